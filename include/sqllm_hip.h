@@ -1,0 +1,197 @@
+/* sqllm_hip.h -- C ABI of libsqllm_hip.so: MI355X (gfx950) implementation of SqueezeLLM's
+ * dense-and-sparse LUT-quantised matvec operator family.
+ *
+ * This header is the drop-in boundary.  It replaces the reference's pybind11 extension
+ * `quant_cuda` (/root/reference/squeezellm/quant_cuda.cpp:112-270, launchers in
+ * squeezellm/quant_cuda_kernel.cu:132-738): every `sqllm_vecquant*` entry point below has the
+ * name, argument order and meaning of the reference function it replaces, with each
+ * torch::Tensor argument replaced by a device pointer and the sizes the reference reads from it
+ * via `.size()` passed explicitly after the tensor arguments, plus the HIP stream to launch on.
+ *
+ * Contract common to all entry points (reference behaviour: SURVEY.md section 8(b)):
+ *   - all pointers are DEVICE pointers on the current HIP device; tensors are contiguous,
+ *     row-major; `vec`, `mul`, `lookup_table`, `vals`, `full_rows` are fp32; `mat*` (qweight),
+ *     `rows`, `cols`, `full_row_indices` are int32;
+ *   - `mul` is ACCUMULATED INTO, never overwritten (the caller pre-loads bias or zeros:
+ *     squeezellm/quant.py:214-219, :316-318);
+ *   - qweight is int32 [height, width] = [K/32*bits, N]; lookup_table is [N, 2^bits];
+ *   - the callee allocates nothing, retains nothing, never synchronises, and enqueues exactly one
+ *     kernel on `stream` (NULL = the legacy default stream, which is what the reference used;
+ *     the Python binding passes torch's current stream so calls are graph-capturable);
+ *   - return value: 0 on success, a negative SQLLM_E_* code for rejected arguments (the reference
+ *     validated nothing and read out of bounds instead), or a positive hipError_t from the launch.
+ *
+ * Shape requirements: K % 32 == 0 and N % 4 == 0 (the reference needed K % 128 == 0 and
+ * N % 128 == 0: quant_cuda_kernel.cu:754,776,841-852).  qweight must be 16-byte aligned.
+ */
+#ifndef SQLLM_HIP_H
+#define SQLLM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQLLM_ABI_VERSION 1
+
+/* error codes (negative; positive return values are hipError_t) */
+#define SQLLM_OK 0
+#define SQLLM_E_BITS (-1)      /* bits not in {3, 4} (quant.py:42-43) */
+#define SQLLM_E_SHAPE (-2)     /* K % 32 != 0, N % 4 != 0, height != K/32*bits, non-positive dims */
+#define SQLLM_E_NULL (-3)      /* a required pointer is NULL */
+#define SQLLM_E_ALIGN (-4)     /* qweight not 16-byte aligned */
+#define SQLLM_E_SPARSE (-5)    /* inconsistent sparse operands (nnz < 0, num_rows != N, topX < 0) */
+#define SQLLM_E_BATCH (-6)     /* batch < 1 or vec_height != K for a batched op */
+#define SQLLM_E_OPTION (-7)    /* unknown option name / bad value */
+
+typedef void* sqllm_stream_t; /* a hipStream_t */
+
+/* ---------------------------------------------------------------------------------------------
+ * Generic descriptor form.  All twelve named entry points are thin adapters over sqllm_launch.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct sqllm_op {
+  int32_t bits;  /* 3 or 4 */
+  int32_t batch; /* 0: matvec op, vec [K], mul [N].  >= 1: *_batched op, vec [batch, K], mul [batch, N] */
+  int32_t K;     /* infeatures  */
+  int32_t N;     /* outfeatures */
+  const float* vec;
+  const int32_t* qweight;     /* [K/32*bits, N] */
+  float* mul;                 /* accumulated into */
+  const float* lookup_table;  /* [N, 2^bits] */
+  /* CSR outliers; rows == NULL -> no sparse term */
+  const int32_t* rows; /* [N + 1] */
+  const int32_t* cols; /* [nnz]   */
+  const float* vals;   /* [nnz]   */
+  int32_t nnz;
+  /* "top-X" dense rows; full_rows == NULL -> no such term */
+  int32_t topX;
+  const float* full_rows;           /* [K, topX] */
+  const int32_t* full_row_indices;  /* [topX]    */
+} sqllm_op;
+
+/* Enqueue one fused kernel computing  mul += W_lut . vec (+ CSR . vec) (+ full_rows^T . vec scattered). */
+int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream);
+
+/* Enqueue `n_ops` ops back to back on `stream` from one host call (a decode pass over a stack of
+ * QuantLinearLUT layers costs one FFI crossing instead of n_ops).  Stops at the first error and
+ * returns it; *n_done (may be NULL) receives the number of ops enqueued. */
+int sqllm_launch_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t stream, int32_t* n_done);
+
+/* ---------------------------------------------------------------------------------------------
+ * The reference operator names.
+ * height/width = mat.size(0)/mat.size(1) of the qweight tensor (quant_cuda_kernel.cu:138-139).
+ * ------------------------------------------------------------------------------------------- */
+
+/* replaces vecquant3matmul_nuq_perchannel / vecquant4matmul_nuq_perchannel
+ * (quant_cuda.cpp:112-125 -> quant_cuda_kernel.cu:132-154 / :157-179) */
+int sqllm_vecquant3matmul_nuq_perchannel(const float* vec, const int32_t* mat, float* mul,
+                                         const float* lookup_table, int height, int width,
+                                         sqllm_stream_t stream);
+int sqllm_vecquant4matmul_nuq_perchannel(const float* vec, const int32_t* mat, float* mul,
+                                         const float* lookup_table, int height, int width,
+                                         sqllm_stream_t stream);
+
+/* replaces vecquant{3,4}matmul_nuq_perchannel_batched (quant_cuda.cpp:126-139 ->
+ * quant_cuda_kernel.cu:182-207 / :210-235); batch = vec.size(0), vec_height = vec.size(1) */
+int sqllm_vecquant3matmul_nuq_perchannel_batched(const float* vec, const int32_t* mat, float* mul,
+                                                 const float* lookup_table, int height, int width,
+                                                 int batch, int vec_height, sqllm_stream_t stream);
+int sqllm_vecquant4matmul_nuq_perchannel_batched(const float* vec, const int32_t* mat, float* mul,
+                                                 const float* lookup_table, int height, int width,
+                                                 int batch, int vec_height, sqllm_stream_t stream);
+
+/* replaces vecquant{3,4}matmul_spmv_nuq_perchannel (quant_cuda.cpp:141-166 ->
+ * quant_cuda_kernel.cu:238-281 / :284-327).  `mat` is the CSR value array (the reference's name),
+ * `mat3`/`mat4` the packed qweight; nnz = cols.size(0). */
+int sqllm_vecquant3matmul_spmv_nuq_perchannel(const int32_t* rows, const int32_t* cols,
+                                              const float* mat, const float* vec, float* mul,
+                                              int num_rows, const int32_t* mat3,
+                                              const float* lookup_table, int height, int width,
+                                              int nnz, sqllm_stream_t stream);
+int sqllm_vecquant4matmul_spmv_nuq_perchannel(const int32_t* rows, const int32_t* cols,
+                                              const float* mat, const float* vec, float* mul,
+                                              int num_rows, const int32_t* mat4,
+                                              const float* lookup_table, int height, int width,
+                                              int nnz, sqllm_stream_t stream);
+
+/* replaces vecquant{3,4}matmul_spmv_nuq_perchannel_batched (quant_cuda.cpp:168-193 ->
+ * quant_cuda_kernel.cu:331-382 / :385-435) */
+int sqllm_vecquant3matmul_spmv_nuq_perchannel_batched(const int32_t* rows, const int32_t* cols,
+                                                      const float* mat, const float* vec,
+                                                      float* mul, int num_rows,
+                                                      const int32_t* mat3,
+                                                      const float* lookup_table, int height,
+                                                      int width, int nnz, int batch,
+                                                      int vec_height, sqllm_stream_t stream);
+int sqllm_vecquant4matmul_spmv_nuq_perchannel_batched(const int32_t* rows, const int32_t* cols,
+                                                      const float* mat, const float* vec,
+                                                      float* mul, int num_rows,
+                                                      const int32_t* mat4,
+                                                      const float* lookup_table, int height,
+                                                      int width, int nnz, int batch,
+                                                      int vec_height, sqllm_stream_t stream);
+
+/* replaces vecquant{3,4}matmul_spmv_hybrid_nuq_perchannel (quant_cuda.cpp:195-224 ->
+ * quant_cuda_kernel.cu:439-506 / :510-577); full_rows is [full_height = K, topX] */
+int sqllm_vecquant3matmul_spmv_hybrid_nuq_perchannel(
+    const int32_t* rows, const int32_t* cols, const float* mat, const float* vec,
+    const float* full_rows, const int32_t* full_row_indices, float* mul, int num_rows,
+    const int32_t* mat3, const float* lookup_table, int height, int width, int nnz, int topX,
+    sqllm_stream_t stream);
+int sqllm_vecquant4matmul_spmv_hybrid_nuq_perchannel(
+    const int32_t* rows, const int32_t* cols, const float* mat, const float* vec,
+    const float* full_rows, const int32_t* full_row_indices, float* mul, int num_rows,
+    const int32_t* mat4, const float* lookup_table, int height, int width, int nnz, int topX,
+    sqllm_stream_t stream);
+
+/* replaces vecquant{3,4}matmul_spmv_hybrid_nuq_perchannel_batched (quant_cuda.cpp:226-255 ->
+ * quant_cuda_kernel.cu:580-657 / :661-738) */
+int sqllm_vecquant3matmul_spmv_hybrid_nuq_perchannel_batched(
+    const int32_t* rows, const int32_t* cols, const float* mat, const float* vec,
+    const float* full_rows, const int32_t* full_row_indices, float* mul, int num_rows,
+    const int32_t* mat3, const float* lookup_table, int height, int width, int nnz, int topX,
+    int batch, int vec_height, sqllm_stream_t stream);
+int sqllm_vecquant4matmul_spmv_hybrid_nuq_perchannel_batched(
+    const int32_t* rows, const int32_t* cols, const float* mat, const float* vec,
+    const float* full_rows, const int32_t* full_row_indices, float* mul, int num_rows,
+    const int32_t* mat4, const float* lookup_table, int height, int width, int nnz, int topX,
+    int batch, int vec_height, sqllm_stream_t stream);
+
+/* The two names squeezellm/quant.py:237-250 / :281-294 call for `balanced=True` layers but the
+ * reference never defined or exported (quant_cuda.cpp:257-270).  Argument order is quant.py's.
+ * `startrows`/`num_threads` describe the reference's intended thread partition; this
+ * implementation balances by nnz on its own and ignores them (they may be NULL/0).
+ * Semantics = the spmv op: mul += W_lut . vec + CSR . vec. */
+int sqllm_vecquant3matmul_spmv_balanced_nuq_perchannel(
+    const int32_t* rows, const int32_t* cols, const int32_t* startrows, const float* mat,
+    const float* vec, float* mul, const int32_t* mat3, const float* lookup_table, int num_rows,
+    int num_threads, int numvals, int height, int width, sqllm_stream_t stream);
+int sqllm_vecquant4matmul_spmv_balanced_nuq_perchannel(
+    const int32_t* rows, const int32_t* cols, const int32_t* startrows, const float* mat,
+    const float* vec, float* mul, const int32_t* mat4, const float* lookup_table, int num_rows,
+    int num_threads, int numvals, int height, int width, sqllm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Library services
+ * ------------------------------------------------------------------------------------------- */
+int sqllm_abi_version(void);
+const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hipError_t values */
+
+/* Launch-geometry knobs (for measurement sweeps; defaults are chosen per shape):
+ *   "target_wgs"      dense workgroups to aim for (default 0 = 2 x CU count)
+ *   "groups_per_wave" force the K-groups each wave walks (default 0 = derived from target_wgs)
+ * Returns SQLLM_E_OPTION for an unknown name. */
+int sqllm_set_option(const char* name, int value);
+int sqllm_get_option(const char* name, int* value);
+
+/* Geometry the library would use for a dense op of this shape (for tests and DESIGN.md tables). */
+typedef struct sqllm_plan {
+  int32_t col_tiles, k_slices, groups_per_wave, dense_blocks, csr_blocks, topx_blocks, grid_x, grid_y;
+} sqllm_plan;
+int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQLLM_HIP_H */

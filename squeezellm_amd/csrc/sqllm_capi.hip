@@ -1,0 +1,277 @@
+// sqllm_capi.hip -- the extern "C" surface declared in include/sqllm_hip.h: argument validation,
+// launch planning, and the reference operator names as thin adapters over sqllm_launch().
+// Replaces the reference's pybind11 layer squeezellm/quant_cuda.cpp:112-270 and the grid math of
+// its launchers squeezellm/quant_cuda_kernel.cu:132-738 (no torch types cross this boundary).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <atomic>
+
+#include "sqllm_hip.h"
+#include "sqllm_kernels.h"
+
+namespace {
+
+std::atomic<int> g_target_wgs{0};
+std::atomic<int> g_groups_per_wave{0};
+std::atomic<int> g_cu_count{0};
+
+int cu_count() {
+  int c = g_cu_count.load(std::memory_order_relaxed);
+  if (c > 0) return c;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+      prop.multiProcessorCount > 0)
+    c = prop.multiProcessorCount;
+  else
+    c = 256;  // MI355X
+  g_cu_count.store(c, std::memory_order_relaxed);
+  return c;
+}
+
+int validate(const sqllm_op* op) {
+  if (!op) return SQLLM_E_NULL;
+  if (op->bits != 3 && op->bits != 4) return SQLLM_E_BITS;
+  if (op->K <= 0 || op->N <= 0 || (op->K % 32) != 0 || (op->N % 4) != 0) return SQLLM_E_SHAPE;
+  if (op->batch < 0) return SQLLM_E_BATCH;
+  if (!op->vec || !op->qweight || !op->mul || !op->lookup_table) return SQLLM_E_NULL;
+  if ((reinterpret_cast<uintptr_t>(op->qweight) & 15u) != 0 ||
+      (reinterpret_cast<uintptr_t>(op->lookup_table) & 15u) != 0)
+    return SQLLM_E_ALIGN;
+  if (op->rows) {
+    if (op->nnz < 0) return SQLLM_E_SPARSE;
+    if (op->nnz > 0 && (!op->cols || !op->vals)) return SQLLM_E_NULL;
+  }
+  if (op->full_rows) {
+    if (op->topX < 0) return SQLLM_E_SPARSE;
+    if (op->topX > 0 && !op->full_row_indices) return SQLLM_E_NULL;
+  }
+  return SQLLM_OK;
+}
+
+// Launch geometry.  The dense part is cut into 256-column tiles x K slices so that about
+// `target` workgroups exist (2 per CU by default: the 7B shapes hold only ~32 KiB of weights per
+// CU, so the grid must be wide rather than deep); every wave walks `gpw` groups (a group = 8 k's
+// for 4-bit, 32 k's for 3-bit), rounded so a wave's range is whole 32-k batches.
+void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm) {
+  const int kK = (op->bits == 4) ? 8 : 32;
+  const int batch_groups = 32 / kK;  // groups per 32-k batch
+  memset(gm, 0, sizeof(*gm));
+  gm->K = op->K;
+  gm->N = op->N;
+  gm->batch = op->batch <= 0 ? 1 : op->batch;
+  gm->col_tiles = (op->N + sqllm::kTileN - 1) / sqllm::kTileN;
+  gm->groups_total = op->K / kK;
+  int gpw = g_groups_per_wave.load(std::memory_order_relaxed);
+  if (gpw <= 0) {
+    int target = g_target_wgs.load(std::memory_order_relaxed);
+    if (target <= 0) target = 2 * cu_count();
+    int slices = (target + gm->col_tiles / 2) / gm->col_tiles;
+    if (slices < 1) slices = 1;
+    gpw = (gm->groups_total + slices * sqllm::kWaves - 1) / (slices * sqllm::kWaves);
+  }
+  gpw = (gpw + batch_groups - 1) / batch_groups * batch_groups;
+  if (gpw < batch_groups) gpw = batch_groups;
+  gm->groups_per_wave = gpw;
+  gm->k_slices = (gm->groups_total + gpw * sqllm::kWaves - 1) / (gpw * sqllm::kWaves);
+  gm->dense_blocks = gm->col_tiles * gm->k_slices;
+  gm->nnz = (op->rows && op->nnz > 0) ? op->nnz : 0;
+  gm->csr_blocks = (gm->nnz + sqllm::kCsrChunk - 1) / sqllm::kCsrChunk;
+  gm->topX = (op->full_rows && op->topX > 0) ? op->topX : 0;
+  gm->topx_blocks = gm->topX ? (op->K + sqllm::kTopxRows - 1) / sqllm::kTopxRows : 0;
+  // dense blocks start at a multiple of 8 so that (dense id % 8) is the XCD of the workgroup
+  gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sqllm_abi_version(void) { return SQLLM_ABI_VERSION; }
+
+const char* sqllm_error_string(int code) {
+  switch (code) {
+    case SQLLM_OK: return "ok";
+    case SQLLM_E_BITS: return "bits must be 3 or 4";
+    case SQLLM_E_SHAPE: return "bad shape: need K % 32 == 0, N % 4 == 0, height == K/32*bits, positive dims";
+    case SQLLM_E_NULL: return "a required pointer is NULL";
+    case SQLLM_E_ALIGN: return "qweight / lookup_table must be 16-byte aligned";
+    case SQLLM_E_SPARSE: return "inconsistent sparse operands";
+    case SQLLM_E_BATCH: return "bad batch / vec_height";
+    case SQLLM_E_OPTION: return "unknown option or bad value";
+    default: break;
+  }
+  if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
+  return "unknown sqllm error";
+}
+
+int sqllm_set_option(const char* name, int value) {
+  if (!name || value < 0) return SQLLM_E_OPTION;
+  if (!strcmp(name, "target_wgs")) { g_target_wgs.store(value); return SQLLM_OK; }
+  if (!strcmp(name, "groups_per_wave")) { g_groups_per_wave.store(value); return SQLLM_OK; }
+  if (!strcmp(name, "cu_count")) { g_cu_count.store(value); return SQLLM_OK; }  // for GPU-less planning tests
+  return SQLLM_E_OPTION;
+}
+
+int sqllm_get_option(const char* name, int* value) {
+  if (!name || !value) return SQLLM_E_OPTION;
+  if (!strcmp(name, "target_wgs")) { *value = g_target_wgs.load(); return SQLLM_OK; }
+  if (!strcmp(name, "groups_per_wave")) { *value = g_groups_per_wave.load(); return SQLLM_OK; }
+  if (!strcmp(name, "cu_count")) { *value = g_cu_count.load(); return SQLLM_OK; }
+  return SQLLM_E_OPTION;
+}
+
+int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
+  if (!plan) return SQLLM_E_NULL;
+  // planning needs shapes only; tolerate NULL data pointers here
+  if (!op) return SQLLM_E_NULL;
+  if (op->bits != 3 && op->bits != 4) return SQLLM_E_BITS;
+  if (op->K <= 0 || op->N <= 0 || (op->K % 32) != 0 || (op->N % 4) != 0) return SQLLM_E_SHAPE;
+  sqllm::KernelGeom gm;
+  make_plan(op, &gm);
+  plan->col_tiles = gm.col_tiles;
+  plan->k_slices = gm.k_slices;
+  plan->groups_per_wave = gm.groups_per_wave;
+  plan->dense_blocks = gm.dense_blocks;
+  plan->csr_blocks = gm.csr_blocks;
+  plan->topx_blocks = gm.topx_blocks;
+  plan->grid_x = gm.dense_block0 + gm.dense_blocks;
+  plan->grid_y = (gm.batch + sqllm::batch_tile(gm.batch) - 1) / sqllm::batch_tile(gm.batch);
+  return SQLLM_OK;
+}
+
+int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream) {
+  int rc = validate(op);
+  if (rc != SQLLM_OK) return rc;
+  sqllm::LaunchArgs a;
+  a.x = op->vec;
+  a.q = reinterpret_cast<const uint32_t*>(op->qweight);
+  a.y = op->mul;
+  a.lut = op->lookup_table;
+  a.rows = op->rows;
+  a.cols = op->cols;
+  a.vals = op->vals;
+  a.full_rows = op->full_rows;
+  a.full_idx = op->full_row_indices;
+  make_plan(op, &a.gm);
+  return static_cast<int>(sqllm::launch_fused(op->bits, a, static_cast<hipStream_t>(stream)));
+}
+
+int sqllm_launch_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t stream, int32_t* n_done) {
+  if (n_done) *n_done = 0;
+  if (n_ops < 0 || (n_ops > 0 && !ops)) return SQLLM_E_NULL;
+  for (int32_t i = 0; i < n_ops; ++i) {
+    int rc = sqllm_launch(&ops[i], stream);
+    if (rc != SQLLM_OK) return rc;
+    if (n_done) *n_done = i + 1;
+  }
+  return SQLLM_OK;
+}
+
+// ---- the reference operator names -------------------------------------------------------------
+
+static int named(int bits, int batch, int vec_height, const float* vec, const int32_t* mat,
+                 float* mul, const float* lut, int height, int width, const int32_t* rows,
+                 const int32_t* cols, const float* vals, int nnz, int num_rows,
+                 const float* full_rows, const int32_t* full_idx, int topX, bool has_csr,
+                 bool has_topx, sqllm_stream_t stream) {
+  if (bits != 3 && bits != 4) return SQLLM_E_BITS;
+  if (height <= 0 || width <= 0 || (height % bits) != 0) return SQLLM_E_SHAPE;
+  sqllm_op op;
+  memset(&op, 0, sizeof(op));
+  op.bits = bits;
+  op.K = height / bits * 32;  // height = K/32*bits (squeezellm/quant.py:48-51)
+  op.N = width;
+  op.batch = batch;
+  if (batch > 0 && vec_height != op.K) return SQLLM_E_BATCH;
+  op.vec = vec;
+  op.qweight = mat;
+  op.mul = mul;
+  op.lookup_table = lut;
+  if (has_csr) {
+    if (num_rows != width) return SQLLM_E_SPARSE;  // CSR rows are output channels (quant.py:233)
+    if (!rows) return SQLLM_E_NULL;
+    op.rows = rows;
+    op.cols = cols;
+    op.vals = vals;
+    op.nnz = nnz;
+  }
+  if (has_topx) {
+    if (topX > 0 && !full_rows) return SQLLM_E_NULL;
+    op.full_rows = topX > 0 ? full_rows : nullptr;
+    op.full_row_indices = full_idx;
+    op.topX = topX;
+  }
+  return sqllm_launch(&op, stream);
+}
+
+#define SQLLM_DENSE(BITS)                                                                          \
+  int sqllm_vecquant##BITS##matmul_nuq_perchannel(const float* vec, const int32_t* mat, float* mul, \
+                                                  const float* lookup_table, int height, int width, \
+                                                  sqllm_stream_t stream) {                          \
+    return named(BITS, 0, 0, vec, mat, mul, lookup_table, height, width, nullptr, nullptr, nullptr, \
+                 0, 0, nullptr, nullptr, 0, false, false, stream);                                  \
+  }                                                                                                 \
+  int sqllm_vecquant##BITS##matmul_nuq_perchannel_batched(                                          \
+      const float* vec, const int32_t* mat, float* mul, const float* lookup_table, int height,      \
+      int width, int batch, int vec_height, sqllm_stream_t stream) {                                \
+    if (batch < 1) return SQLLM_E_BATCH;                                                            \
+    return named(BITS, batch, vec_height, vec, mat, mul, lookup_table, height, width, nullptr,      \
+                 nullptr, nullptr, 0, 0, nullptr, nullptr, 0, false, false, stream);                \
+  }
+
+#define SQLLM_SPMV(BITS)                                                                            \
+  int sqllm_vecquant##BITS##matmul_spmv_nuq_perchannel(                                             \
+      const int32_t* rows, const int32_t* cols, const float* mat, const float* vec, float* mul,     \
+      int num_rows, const int32_t* matq, const float* lookup_table, int height, int width, int nnz, \
+      sqllm_stream_t stream) {                                                                      \
+    return named(BITS, 0, 0, vec, matq, mul, lookup_table, height, width, rows, cols, mat, nnz,     \
+                 num_rows, nullptr, nullptr, 0, true, false, stream);                               \
+  }                                                                                                 \
+  int sqllm_vecquant##BITS##matmul_spmv_nuq_perchannel_batched(                                     \
+      const int32_t* rows, const int32_t* cols, const float* mat, const float* vec, float* mul,     \
+      int num_rows, const int32_t* matq, const float* lookup_table, int height, int width, int nnz, \
+      int batch, int vec_height, sqllm_stream_t stream) {                                           \
+    if (batch < 1) return SQLLM_E_BATCH;                                                            \
+    return named(BITS, batch, vec_height, vec, matq, mul, lookup_table, height, width, rows, cols,  \
+                 mat, nnz, num_rows, nullptr, nullptr, 0, true, false, stream);                     \
+  }                                                                                                 \
+  int sqllm_vecquant##BITS##matmul_spmv_balanced_nuq_perchannel(                                    \
+      const int32_t* rows, const int32_t* cols, const int32_t* startrows, const float* mat,         \
+      const float* vec, float* mul, const int32_t* matq, const float* lookup_table, int num_rows,   \
+      int num_threads, int numvals, int height, int width, sqllm_stream_t stream) {                 \
+    (void)startrows;                                                                                \
+    (void)num_threads;                                                                              \
+    return named(BITS, 0, 0, vec, matq, mul, lookup_table, height, width, rows, cols, mat, numvals, \
+                 num_rows, nullptr, nullptr, 0, true, false, stream);                               \
+  }
+
+#define SQLLM_HYBRID(BITS)                                                                          \
+  int sqllm_vecquant##BITS##matmul_spmv_hybrid_nuq_perchannel(                                      \
+      const int32_t* rows, const int32_t* cols, const float* mat, const float* vec,                 \
+      const float* full_rows, const int32_t* full_row_indices, float* mul, int num_rows,            \
+      const int32_t* matq, const float* lookup_table, int height, int width, int nnz, int topX,     \
+      sqllm_stream_t stream) {                                                                      \
+    return named(BITS, 0, 0, vec, matq, mul, lookup_table, height, width, rows, cols, mat, nnz,     \
+                 num_rows, full_rows, full_row_indices, topX, true, true, stream);                  \
+  }                                                                                                 \
+  int sqllm_vecquant##BITS##matmul_spmv_hybrid_nuq_perchannel_batched(                              \
+      const int32_t* rows, const int32_t* cols, const float* mat, const float* vec,                 \
+      const float* full_rows, const int32_t* full_row_indices, float* mul, int num_rows,            \
+      const int32_t* matq, const float* lookup_table, int height, int width, int nnz, int topX,     \
+      int batch, int vec_height, sqllm_stream_t stream) {                                           \
+    if (batch < 1) return SQLLM_E_BATCH;                                                            \
+    return named(BITS, batch, vec_height, vec, matq, mul, lookup_table, height, width, rows, cols,  \
+                 mat, nnz, num_rows, full_rows, full_row_indices, topX, true, true, stream);        \
+  }
+
+SQLLM_DENSE(3)
+SQLLM_DENSE(4)
+SQLLM_SPMV(3)
+SQLLM_SPMV(4)
+SQLLM_HYBRID(3)
+SQLLM_HYBRID(4)
+
+}  // extern "C"

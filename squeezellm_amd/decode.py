@@ -1,0 +1,74 @@
+"""Whole-pass launchers: a decode step over a stack of QuantLinearLUT layers as ONE host call.
+
+The reference pays a Python -> pybind -> launch round trip per operator (and 1-3 launches inside
+each, quant_cuda_kernel.cu:439-506); at batch 1 the 7B model's per-linear budget is ~1-4 us, far
+below an eager launch (~3-4 us of host time).  `OpSequence` pre-marshals every operand once into a
+C array of `sqllm_op` descriptors (include/sqllm_hip.h) and then
+  * `launch()`  enqueues the whole pass through one FFI crossing (sqllm_launch_sequence), or
+  * `graph()`   captures that into a HIP graph for replay.
+All launches go to torch's current stream; nothing here synchronises.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class OpSequence:
+    """A fixed list of ops `ys[i] += layer_i(xs[i])` with all pointers resolved up front."""
+
+    def __init__(self, layers, xs, ys, batched: bool = False):
+        if not (len(layers) == len(xs) == len(ys)):
+            raise ValueError("layers, xs, ys must have equal length")
+        self.n = len(layers)
+        self._keep = (layers, xs, ys)  # keep the tensors alive as long as the descriptors
+        self.ops = (_lib.SqllmOp * self.n)()
+        self.device = xs[0].device if self.n else torch.device("cuda")
+        for i, (lay, x, y) in enumerate(zip(layers, xs, ys)):
+            for name, t, dt in (("x", x, torch.float32), ("y", y, torch.float32),
+                                ("qweight", lay["qweight"], torch.int32),
+                                ("lookup_table", lay["lookup_table"], torch.float32)):
+                if t.dtype != dt or not t.is_cuda or not t.is_contiguous():
+                    raise ValueError(f"op {i}: {name} must be a contiguous {dt} GPU tensor")
+            K, N = lay["K"], lay["N"]
+            batch = x.shape[0] if batched else 0
+            if x.numel() != max(batch, 1) * K or y.numel() != max(batch, 1) * N:
+                raise ValueError(f"op {i}: x/y sizes do not match K={K}, N={N}, batch={batch}")
+            o = self.ops[i]
+            o.bits, o.batch, o.K, o.N = lay["bits"], batch, K, N
+            o.vec, o.qweight, o.mul, o.lookup_table = x.data_ptr(), lay["qweight"].data_ptr(), y.data_ptr(), lay["lookup_table"].data_ptr()
+            if lay.get("vals") is not None:
+                o.rows, o.cols, o.vals = _ptr(lay["rows"]), _ptr(lay["cols"]), _ptr(lay["vals"])
+                o.nnz = lay["vals"].numel()
+            if lay.get("full_rows") is not None:
+                o.full_rows, o.full_row_indices = _ptr(lay["full_rows"]), _ptr(lay["full_row_indices"])
+                o.topX = lay["full_rows"].shape[1]
+        self._lib = _lib.load()
+        self._done = ctypes.c_int32(0)
+
+    def launch(self) -> None:
+        """Enqueue all ops on the current stream of the sequence's device (one FFI crossing)."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.sqllm_launch_sequence(self.ops, self.n, stream, ctypes.byref(self._done))
+        if rc != 0:
+            _lib.check(rc, f"sqllm_launch_sequence (op {self._done.value} of {self.n})")
+
+    def graph(self, warmup: int = 1) -> "torch.cuda.CUDAGraph":
+        """Capture one pass into a HIP graph (replay with .replay())."""
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.launch()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.launch()
+        return g

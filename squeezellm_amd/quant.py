@@ -1,0 +1,130 @@
+"""QuantLinearLUT for MI355X -- host-side mirror of the reference layer
+(/root/reference/squeezellm/quant.py:28-383): same constructor signature, same buffer names /
+shapes / dtypes (so reference checkpoints load with `load_state_dict`), same choice of operator
+per configuration and the same pre/post-processing around it.  The reference's own quant.py also
+runs unchanged on top of the top-level `quant_cuda` shim; this module exists so
+that the path can be exercised where the reference tree is absent, and to host the MI355X-only
+conveniences (`from_operands`, `operands`).
+
+Packing (`pack2`, quant.py:97-208) is offline tooling and out of scope here; see oracle/ for the
+format restatement used by the tests.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import quant_cuda
+
+
+class QuantLinearLUT(nn.Module):
+    """Drop-in for the reference class of the same name (quant.py:28-95 buffers, :211-383 forward)."""
+
+    def __init__(self, bits, infeatures, outfeatures, bias, include_sparse=False, numvals=0, topX=0,
+                 balanced=False, num_nonzero_per_thread=10):
+        super().__init__()
+        if bits not in (3, 4):
+            raise NotImplementedError("Only 3 and 4 bits is supported.")  # quant.py:42-43
+        self.bits, self.infeatures, self.outfeatures = bits, infeatures, outfeatures
+        self.include_sparse, self.numvals, self.topX, self.balanced = include_sparse, numvals, topX, balanced
+        i32, f32 = torch.int32, torch.float32
+        self.register_buffer("qweight", torch.zeros((infeatures // 32 * bits, outfeatures), dtype=i32))
+        self.include_bias = bool(bias)
+        if self.include_bias:
+            self.register_buffer("bias", torch.zeros(outfeatures, dtype=f32))
+        else:
+            self.bias = None
+        self.register_buffer("lookup_table", torch.zeros((outfeatures, 2**bits), dtype=f32))
+        if numvals > 0:  # quant.py:66-71
+            self.register_buffer("rows", torch.zeros(outfeatures + 1, dtype=i32))
+            self.register_buffer("cols", torch.zeros(numvals, dtype=i32))
+            self.register_buffer("vals", torch.zeros(numvals, dtype=f32))
+        if topX > 0:  # quant.py:74-80
+            self.register_buffer("full_rows", torch.zeros((infeatures, topX), dtype=f32))
+            self.register_buffer("full_row_indices", torch.zeros(topX, dtype=i32))
+        if include_sparse and balanced and numvals > 0:  # quant.py:84-95
+            nt = int((numvals + num_nonzero_per_thread - 1) / num_nonzero_per_thread)
+            self.num_threads = 128 * math.ceil(nt / 128)
+            self.register_buffer("startrows", torch.zeros(self.num_threads, dtype=i32))
+
+    # -- which operator a configuration maps to: hybrid > balanced > spmv > dense (quant.py:224-265;
+    #    the batched branch has no balanced arm, :322-349)
+    def op_kind(self, batched: bool) -> str:
+        if self.include_sparse and self.topX > 0:
+            return "spmv_hybrid"
+        if self.include_sparse and self.balanced and not batched:
+            return "spmv_balanced"
+        if self.include_sparse:
+            return "spmv"
+        return "dense"
+
+    def _call(self, x32: torch.Tensor, y: torch.Tensor, batched: bool) -> None:
+        kind = self.op_kind(batched)
+        sfx = "_batched" if batched else ""
+        b = self.bits
+        if kind == "dense":
+            getattr(quant_cuda, f"vecquant{b}matmul_nuq_perchannel{sfx}")(x32, self.qweight, y, self.lookup_table)
+        elif kind == "spmv":
+            getattr(quant_cuda, f"vecquant{b}matmul_spmv_nuq_perchannel{sfx}")(
+                self.rows, self.cols, self.vals, x32, y, self.outfeatures, self.qweight, self.lookup_table)
+        elif kind == "spmv_hybrid":
+            getattr(quant_cuda, f"vecquant{b}matmul_spmv_hybrid_nuq_perchannel{sfx}")(
+                self.rows, self.cols, self.vals, x32, self.full_rows, self.full_row_indices, y,
+                self.outfeatures, self.qweight, self.lookup_table)
+        else:
+            getattr(quant_cuda, f"vecquant{b}matmul_spmv_balanced_nuq_perchannel")(
+                self.rows, self.cols, self.startrows, self.vals, x32, y, self.qweight, self.lookup_table,
+                self.outfeatures, self.num_threads, self.numvals)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        dtype = x.dtype
+        if x.shape[-1] == x.numel():  # single token: the matvec ops (quant.py:212-312)
+            y = self.bias.clone() if self.bias is not None else torch.zeros(
+                self.outfeatures, device=x.device, dtype=torch.float32)
+            self._call(x.float().contiguous(), y, batched=False)
+            return y.to(dtype).reshape(*x.shape[:-1], self.outfeatures)
+        # several rows: the *_batched ops; bias is added AFTER the cast back (quant.py:313-383)
+        x2 = x.reshape(-1, x.shape[-1])
+        out = torch.zeros((x2.shape[0], self.outfeatures), device=x.device, dtype=torch.float32)
+        self._call(x2.float().contiguous(), out, batched=True)
+        out = out.to(dtype).reshape(*x.shape[:-1], self.outfeatures)
+        return out + self.bias if self.bias is not None else out
+
+    # -- MI355X-side conveniences -------------------------------------------------------------
+    @classmethod
+    def from_operands(cls, layer: dict, balanced: bool = False) -> "QuantLinearLUT":
+        """Wrap already-packed operands (e.g. squeezellm_amd.synth.make_layer) without copying."""
+        nnz = 0 if layer.get("vals") is None else layer["vals"].numel()
+        topX = 0 if layer.get("full_rows") is None else layer["full_rows"].shape[1]
+        m = cls(layer["bits"], layer["K"], layer["N"], layer.get("bias") is not None,
+                include_sparse=nnz > 0, numvals=nnz, topX=topX, balanced=balanced)
+        m.qweight, m.lookup_table = layer["qweight"], layer["lookup_table"]
+        if layer.get("bias") is not None:
+            m.bias = layer["bias"]
+        if nnz:
+            m.rows, m.cols, m.vals = layer["rows"], layer["cols"], layer["vals"]
+            if balanced:
+                m.startrows = torch.zeros(m.num_threads, dtype=torch.int32, device=layer["vals"].device)
+        if topX:
+            m.full_rows, m.full_row_indices = layer["full_rows"], layer["full_row_indices"]
+        return m
+
+
+def make_quant_lut(module, names, bits, name="", include_sparse=False, numvals=None, topX=0, balanced=False,
+                   num_nonzero_per_thread=10):
+    """Swap the nn.Linear children listed in `names` for QuantLinearLUT, recursively
+    (reference: quant.py:386-435)."""
+    if isinstance(module, QuantLinearLUT):
+        return
+    for child_name, child in list(module.named_children()):
+        full = f"{name}.{child_name}" if name else child_name
+        if full in names:
+            setattr(module, child_name, QuantLinearLUT(
+                bits, child.in_features, child.out_features, child.bias is not None,
+                include_sparse=include_sparse, numvals=(numvals[full] if numvals is not None else 0),
+                topX=topX, balanced=balanced, num_nonzero_per_thread=num_nonzero_per_thread))
+        else:
+            make_quant_lut(child, names, bits, full, include_sparse=include_sparse, numvals=numvals, topX=topX,
+                           balanced=balanced, num_nonzero_per_thread=num_nonzero_per_thread)

@@ -1,0 +1,118 @@
+"""Layer-sharded decode over the GPUs of one node: one process per GPU, `torch.distributed` with
+the "nccl" backend (= RCCL over xGMI on ROCm).
+
+The reference has no multi-GPU code.  The quantised-linear path shards naturally
+BY LAYER: every QuantLinearLUT is an independent unit, and the only thing that crosses a stage
+boundary is the hidden state of the token being decoded (2 * hidden bytes in fp16: 8 KiB for 7B,
+16 KiB for 65B).  BASELINE.json's north_star names an RCCL all-gather for this exchange.
+
+Scheme (`RingPipeline`): rank r owns the contiguous layer range `partition_layers(L, W)[r]`.  W
+independent sequences are decoded at once, one per stage, rotating around the ring:
+
+    every tick, on every rank:   h_out = stage_r(h_in)                 # this rank's layers
+                                 all_gather(buf[W, hidden], h_out)      # ONE small collective
+                                 h_in  = buf[(r - 1) mod W]             # predecessor's output
+
+After W ticks every sequence has passed through all W stages once, i.e. advanced by one token; the
+output of the last stage wraps around to stage 0 as the next token's input (autoregressive ring).
+So the job produces one token per tick, tick = (single-GPU pass time) / W + all-gather latency.
+The payload is tiny (W * hidden * 2 bytes <= 128 KiB), hence latency-bound; xGMI bandwidth is
+irrelevant here and a ring collective's per-link limit never shows.  Every rank executes the
+identical sequence of collectives, so the schedule cannot deadlock.
+
+The exchange logic is backend-agnostic and is covered on CPU with gloo (tests/test_sharding_cpu.py)
+by injecting a CPU stage function; the product stage (`DecodeStage`) launches the HIP kernels.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def partition_layers(n_layers: int, world_size: int) -> List[Tuple[int, int]]:
+    """Contiguous, balanced [start, end) layer ranges; the first n_layers % world_size ranks get
+    one extra layer.  Ranks beyond n_layers get empty ranges."""
+    if n_layers < 0 or world_size < 1:
+        raise ValueError("need n_layers >= 0 and world_size >= 1")
+    base, extra = divmod(n_layers, world_size)
+    out, start = [], 0
+    for r in range(world_size):
+        n = base + (1 if r < extra else 0)
+        out.append((start, start + n))
+        start += n
+    return out
+
+
+class RingPipeline:
+    """The tick loop described in the module docstring.
+
+    stage_fn(h_in) -> h_out : both 1-D tensors of `hidden` elements, dtype `dtype`, on `device`;
+    it must enqueue its work on the current stream and must not synchronise."""
+
+    def __init__(self, stage_fn: Callable[[torch.Tensor], torch.Tensor], hidden: int, *, rank: int, world_size: int,
+                 device, dtype=torch.float16, group=None, h0: torch.Tensor | None = None):
+        self.stage_fn, self.hidden, self.rank, self.world = stage_fn, hidden, rank, world_size
+        self.group = group
+        self.buf = torch.zeros((world_size, hidden), device=device, dtype=dtype)
+        self.h_in = torch.zeros(hidden, device=device, dtype=dtype) if h0 is None else h0.to(device=device, dtype=dtype).clone()
+        self._chunks = list(self.buf.unbind(0))
+        self._use_flat = hasattr(dist, "all_gather_into_tensor") and (dist.get_backend(group) != "gloo" if dist.is_initialized() else True)
+        self.ticks = 0
+
+    def tick(self) -> torch.Tensor:
+        h_out = self.stage_fn(self.h_in)
+        if self.world == 1:
+            self.buf[0].copy_(h_out)
+        elif self._use_flat:
+            dist.all_gather_into_tensor(self.buf, h_out.contiguous(), group=self.group)
+        else:  # gloo (CPU tests): list form
+            dist.all_gather(self._chunks, h_out.contiguous(), group=self.group)
+        self.h_in.copy_(self.buf[(self.rank - 1) % self.world])
+        self.ticks += 1
+        return h_out
+
+    def run(self, n_ticks: int) -> None:
+        for _ in range(n_ticks):
+            self.tick()
+
+
+class DecodeStage:
+    """This rank's slice of a synthetic decoder stack as a stage function: hidden in -> the stage's
+    quantised linears (one FFI crossing, squeezellm_amd.decode.OpSequence) -> hidden out.
+
+    Dataflow of the synthetic stage: every linear whose K equals `hidden` reads the received hidden
+    state (fp32 copy), the others read a fixed random activation of their own width; the stage
+    output is the last linear whose N equals `hidden`, RMS-normalised so that values stay O(1)
+    around the ring.  All `mul` buffers live in one arena that is zeroed once per tick
+    (the `torch.zeros` of QuantLinearLUT.forward, quant.py:218)."""
+
+    def __init__(self, layers: Sequence[dict], hidden: int, device, seed: int = 0):
+        from .decode import OpSequence
+
+        self.hidden, self.device = hidden, device
+        g = torch.Generator(device=device).manual_seed(seed)
+        self.x_hidden = torch.zeros(hidden, device=device, dtype=torch.float32)
+        total_n = sum(l["N"] for l in layers)
+        self.arena = torch.zeros(max(total_n, 1), device=device, dtype=torch.float32)
+        xs, ys, off = [], [], 0
+        self.out_idx = None
+        for i, l in enumerate(layers):
+            xs.append(self.x_hidden if l["K"] == hidden else torch.randn(l["K"], device=device, generator=g, dtype=torch.float32))
+            ys.append(self.arena[off:off + l["N"]])
+            off += l["N"]
+            if l["N"] == hidden:
+                self.out_idx = i
+        self.ys = ys
+        self.seq = OpSequence(list(layers), xs, ys) if layers else None
+
+    def __call__(self, h_in: torch.Tensor) -> torch.Tensor:
+        if self.seq is None or self.out_idx is None:
+            return h_in  # a rank without layers passes the hidden state through
+        self.x_hidden.copy_(h_in)  # fp16 -> fp32 (the x.float() of quant.py:223)
+        self.arena.zero_()
+        self.seq.launch()
+        y = self.ys[self.out_idx]
+        y = y * torch.rsqrt(y.pow(2).mean() + 1e-6)
+        return y.to(h_in.dtype)
