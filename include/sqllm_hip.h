@@ -78,6 +78,15 @@ int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream);
  * returns it; *n_done (may be NULL) receives the number of ops enqueued. */
 int sqllm_launch_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t stream, int32_t* n_done);
 
+/* Measurement aid (used by bench.py's roofline leg, never on the serving path): enqueue the ops like
+ * sqllm_launch_sequence, but attach a start/stop event pair to EVERY kernel dispatch
+ * (hipExtLaunchKernelGGL), so that each kernel's own device-side duration -- the quantity
+ * rocprofv3 --kernel-trace reports -- is available without a profiler.  Runs `reps` passes,
+ * synchronises `stream` after each, and writes the per-op average in microseconds to
+ * avg_us[0..n_ops).  Blocks the host; not graph-capturable. */
+int sqllm_profile_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t stream, int32_t reps,
+                           float* avg_us);
+
 /* ---------------------------------------------------------------------------------------------
  * The reference operator names.
  * height/width = mat.size(0)/mat.size(1) of the qweight tensor (quant_cuda_kernel.cu:138-139).

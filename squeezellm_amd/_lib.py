@@ -56,6 +56,7 @@ _BAL = [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]
 SIGNATURES = {
     "sqllm_launch": [POINTER(SqllmOp), P],
     "sqllm_launch_sequence": [POINTER(SqllmOp), c_int32, P, POINTER(c_int32)],
+    "sqllm_profile_sequence": [POINTER(SqllmOp), c_int32, P, c_int32, POINTER(ctypes.c_float)],
     "sqllm_abi_version": [],
     "sqllm_error_string": [c_int],
     "sqllm_set_option": [c_char_p, c_int],

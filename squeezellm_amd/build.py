@@ -41,10 +41,12 @@ def is_stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/*.hip -> squeezellm_amd/libsqllm_hip.so (cross-compiles without a GPU)."""
+    """Compile csrc/*.hip -> squeezellm_amd/libsqllm_hip.so (cross-compiles without a GPU).
+    SQLLM_ABLATION=1 in the environment adds the measurement-only ablation kernel variants."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [hipcc(), f"--offload-arch={ARCH}", *FLAGS, "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
+    extra = ["-DSQLLM_ABLATION_BUILD"] if os.environ.get("SQLLM_ABLATION") == "1" else []
+    cmd = [hipcc(), f"--offload-arch={ARCH}", *FLAGS, *extra, "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -13,9 +13,14 @@
 
 namespace {
 
+constexpr int kDefaultWaves = 8;
 std::atomic<int> g_target_wgs{0};
 std::atomic<int> g_groups_per_wave{0};
 std::atomic<int> g_cu_count{0};
+std::atomic<int> g_ablate{0};
+std::atomic<int> g_variant{0};
+std::atomic<int> g_waves{0};
+std::atomic<int> g_sparse_last{0};
 
 int cu_count() {
   int c = g_cu_count.load(std::memory_order_relaxed);
@@ -51,31 +56,38 @@ int validate(const sqllm_op* op) {
   return SQLLM_OK;
 }
 
-// Launch geometry.  The dense part is cut into 256-column tiles x K slices so that about
-// `target` workgroups exist (2 per CU by default: the 7B shapes hold only ~32 KiB of weights per
-// CU, so the grid must be wide rather than deep); every wave walks `gpw` groups (a group = 8 k's
-// for 4-bit, 32 k's for 3-bit), rounded so a wave's range is whole 32-k batches.
+// Launch geometry.  The dense part is cut into 64-column tiles x K slices so that about `target`
+// workgroups exist (2 per CU by default, 8 waves each = 16 waves per CU: the 7B shapes hold only
+// ~32-90 KiB of weights per CU, so the grid must be wide rather than deep).  A slice is a whole
+// number of workgroup steps (waves x 4 units) so only the last slice has a ragged end.
 void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm) {
   const int kK = (op->bits == 4) ? 8 : 32;
-  const int batch_groups = 32 / kK;  // groups per 32-k batch
   memset(gm, 0, sizeof(*gm));
   gm->K = op->K;
   gm->N = op->N;
   gm->batch = op->batch <= 0 ? 1 : op->batch;
   gm->col_tiles = (op->N + sqllm::kTileN - 1) / sqllm::kTileN;
-  gm->groups_total = op->K / kK;
-  int gpw = g_groups_per_wave.load(std::memory_order_relaxed);
-  if (gpw <= 0) {
+  gm->units_total = op->K / kK;
+  int waves = g_waves.load(std::memory_order_relaxed);
+  if (waves != 4 && waves != 8 && waves != 16) waves = kDefaultWaves;
+  gm->waves = waves;
+  const int step = waves * 4;  // units one workgroup step covers
+  int upw = g_groups_per_wave.load(std::memory_order_relaxed) * waves;
+  if (upw <= 0) {
     int target = g_target_wgs.load(std::memory_order_relaxed);
-    if (target <= 0) target = 2 * cu_count();
+    if (target <= 0) {
+      // measured on MI355X (tools/sweep.py): layers under ~12 MB of packed weights run best with one
+      // 8-wave workgroup per CU, larger ones with ~2.5 per CU
+      const double mb = (double)op->K * op->N * op->bits / 8.0 / 1e6;
+      target = mb <= 12.0 ? cu_count() : cu_count() * 5 / 2;
+    }
     int slices = (target + gm->col_tiles / 2) / gm->col_tiles;
     if (slices < 1) slices = 1;
-    gpw = (gm->groups_total + slices * sqllm::kWaves - 1) / (slices * sqllm::kWaves);
+    upw = (gm->units_total + slices - 1) / slices;
   }
-  gpw = (gpw + batch_groups - 1) / batch_groups * batch_groups;
-  if (gpw < batch_groups) gpw = batch_groups;
-  gm->groups_per_wave = gpw;
-  gm->k_slices = (gm->groups_total + gpw * sqllm::kWaves - 1) / (gpw * sqllm::kWaves);
+  upw = (upw + step - 1) / step * step;
+  gm->units_per_wg = upw;
+  gm->k_slices = (gm->units_total + upw - 1) / upw;
   gm->dense_blocks = gm->col_tiles * gm->k_slices;
   gm->nnz = (op->rows && op->nnz > 0) ? op->nnz : 0;
   gm->csr_blocks = (gm->nnz + sqllm::kCsrChunk - 1) / sqllm::kCsrChunk;
@@ -83,6 +95,8 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm) {
   gm->topx_blocks = gm->topX ? (op->K + sqllm::kTopxRows - 1) / sqllm::kTopxRows : 0;
   // dense blocks start at a multiple of 8 so that (dense id % 8) is the XCD of the workgroup
   gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
+  gm->sparse_last = g_sparse_last.load(std::memory_order_relaxed);
+  if (gm->sparse_last) gm->dense_block0 = gm->csr_blocks + gm->topx_blocks;  // grid = dense + sparse
 }
 
 }  // namespace
@@ -111,7 +125,17 @@ int sqllm_set_option(const char* name, int value) {
   if (!name || value < 0) return SQLLM_E_OPTION;
   if (!strcmp(name, "target_wgs")) { g_target_wgs.store(value); return SQLLM_OK; }
   if (!strcmp(name, "groups_per_wave")) { g_groups_per_wave.store(value); return SQLLM_OK; }
+  if (!strcmp(name, "waves")) {
+    if (value != 0 && value != 4 && value != 8 && value != 16) return SQLLM_E_OPTION;
+    g_waves.store(value);
+    return SQLLM_OK;
+  }
+  if (!strcmp(name, "sparse_last")) { g_sparse_last.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { g_cu_count.store(value); return SQLLM_OK; }  // for GPU-less planning tests
+#ifdef SQLLM_ABLATION_BUILD
+  if (!strcmp(name, "ablate")) { g_ablate.store(value); return SQLLM_OK; }
+  if (!strcmp(name, "variant")) { g_variant.store(value); return SQLLM_OK; }
+#endif
   return SQLLM_E_OPTION;
 }
 
@@ -119,6 +143,7 @@ int sqllm_get_option(const char* name, int* value) {
   if (!name || !value) return SQLLM_E_OPTION;
   if (!strcmp(name, "target_wgs")) { *value = g_target_wgs.load(); return SQLLM_OK; }
   if (!strcmp(name, "groups_per_wave")) { *value = g_groups_per_wave.load(); return SQLLM_OK; }
+  if (!strcmp(name, "waves")) { *value = g_waves.load(); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { *value = g_cu_count.load(); return SQLLM_OK; }
   return SQLLM_E_OPTION;
 }
@@ -133,7 +158,7 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   make_plan(op, &gm);
   plan->col_tiles = gm.col_tiles;
   plan->k_slices = gm.k_slices;
-  plan->groups_per_wave = gm.groups_per_wave;
+  plan->groups_per_wave = gm.units_per_wg;
   plan->dense_blocks = gm.dense_blocks;
   plan->csr_blocks = gm.csr_blocks;
   plan->topx_blocks = gm.topx_blocks;
@@ -142,10 +167,14 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   return SQLLM_OK;
 }
 
-int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream) {
+static int launch_with_events(const sqllm_op* op, sqllm_stream_t stream, hipEvent_t e0, hipEvent_t e1) {
   int rc = validate(op);
   if (rc != SQLLM_OK) return rc;
   sqllm::LaunchArgs a;
+  a.ev_start = e0;
+  a.ev_stop = e1;
+  a.ablate = g_ablate.load(std::memory_order_relaxed);
+  a.variant = g_variant.load(std::memory_order_relaxed);
   a.x = op->vec;
   a.q = reinterpret_cast<const uint32_t*>(op->qweight);
   a.y = op->mul;
@@ -157,6 +186,39 @@ int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream) {
   a.full_idx = op->full_row_indices;
   make_plan(op, &a.gm);
   return static_cast<int>(sqllm::launch_fused(op->bits, a, static_cast<hipStream_t>(stream)));
+}
+
+int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream) {
+  return launch_with_events(op, stream, nullptr, nullptr);
+}
+
+int sqllm_profile_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t stream, int32_t reps,
+                           float* avg_us) {
+  if (n_ops < 0 || reps < 1 || (n_ops > 0 && (!ops || !avg_us))) return SQLLM_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipEvent_t* ev = new hipEvent_t[2 * (size_t)n_ops];
+  int rc = SQLLM_OK;
+  int made = 0;
+  for (; made < 2 * n_ops; ++made)
+    if (hipEventCreate(&ev[made]) != hipSuccess) { rc = (int)hipGetLastError(); break; }
+  for (int i = 0; i < n_ops; ++i) avg_us[i] = 0.f;
+  for (int r = 0; r < reps && rc == SQLLM_OK; ++r) {
+    for (int i = 0; i < n_ops && rc == SQLLM_OK; ++i)
+      rc = launch_with_events(&ops[i], stream, ev[2 * i], ev[2 * i + 1]);
+    if (rc != SQLLM_OK) break;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { rc = (int)e; break; }
+    for (int i = 0; i < n_ops; ++i) {
+      float ms = 0.f;
+      e = hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+      if (e != hipSuccess) { rc = (int)e; break; }
+      avg_us[i] += ms * 1000.f;
+    }
+  }
+  for (int i = 0; i < n_ops; ++i) avg_us[i] /= (float)reps;
+  for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+  delete[] ev;
+  return rc;
 }
 
 int sqllm_launch_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t stream, int32_t* n_done) {

@@ -5,33 +5,37 @@
 
 namespace sqllm {
 
-constexpr int kThreads = 256;      // workgroup size: 4 wave64
-constexpr int kWaves = 4;
-constexpr int kTileN = 256;        // output columns per dense tile = 64 lanes x 4 (one dwordx4 each)
+constexpr int kTileN = 64;         // output columns per dense tile = 16 lanes x 4 (one dwordx4 each)
 constexpr int kCsrChunk = 1024;    // non-zeros per CSR workgroup
 constexpr int kCsrSpanMax = 2048;  // CSR rows a chunk may span and still accumulate in LDS
 constexpr int kTopxRows = 128;     // k's per top-X slab
 constexpr int kTopxLds = 1024;     // topX up to which slab sums are kept in LDS
 constexpr int kMaxBatchTile = 8;   // batch rows handled per weight pass
 
-// LDS floats: max over roles of
-//   dense: codebooks 4 * 16 * 64 = 4096 (w4) ; cross-wave reduction kWaves * BT * 256 <= 8192
-//   csr  : kCsrSpanMax ints + kCsrSpanMax floats = 4096
+// LDS floats of one kernel instantiation: max over roles of
+//   dense: codebooks 4 sub-tables * lut_entries * (64 slots for 4-bit, 32 for 3-bit) ; cross-wave
+//          reduction waves * CB * 64
+//   csr  : kCsrSpanMax ints + kCsrSpanMax floats
 //   topx : kTopxLds
-constexpr int kLdsFloats = kWaves * kMaxBatchTile * kTileN;
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int lds_floats(int lut_entries, int waves, int cb) {
+  return cmax(cmax(4 * lut_entries * (lut_entries == 16 ? 64 : 32), waves * cb * kTileN), cmax(2 * kCsrSpanMax, kTopxLds));
+}
 
 // Launch geometry, computed on the host (sqllm_capi.hip: make_plan) and passed by value.
 struct KernelGeom {
   int K, N, batch;
-  int col_tiles;        // ceil(N / 256)
-  int groups_total;     // K / 8 (w4 rows) or K / 32 (w3 three-row groups)
-  int groups_per_wave;  // groups each wave walks; a workgroup covers 4x that
-  int k_slices;         // ceil(groups_total / (4 * groups_per_wave))
+  int col_tiles;        // ceil(N / 64)
+  int units_total;      // K / 8 (w4: qweight rows) or K / 32 (w3: three-row units)
+  int waves;            // waves per workgroup (4, 8 or 16): selects the kernel instantiation
+  int units_per_wg;     // K-slice length of a workgroup, in units (a multiple of waves * 4)
+  int k_slices;         // ceil(units_total / units_per_wg)
   int dense_blocks;     // col_tiles * k_slices
   int dense_block0;     // first dense blockIdx.x (csr + topx blocks rounded up to a multiple of 8)
   int csr_blocks;       // ceil(nnz / kCsrChunk), 0 without a sparse term
   int topx_blocks;      // ceil(K / kTopxRows), 0 without a top-X term
   int nnz, topX;
+  int sparse_last;      // 1: CSR / top-X workgroups come after the dense ones in the grid
 };
 
 struct LaunchArgs {
@@ -45,6 +49,10 @@ struct LaunchArgs {
   const float* full_rows;
   const int* full_idx;
   KernelGeom gm;
+  hipEvent_t ev_start = nullptr;  // optional: recorded at this kernel's begin / end (profiling aid)
+  hipEvent_t ev_stop = nullptr;
+  int ablate = 0;   // measurement builds only (SQLLM_ABLATION_BUILD)
+  int variant = 0;  // measurement builds only: waves * 10 + prefetch depth
 };
 
 // batch rows handled per weight pass for a given batch size (template instantiations 1/2/4/8)

@@ -60,6 +60,17 @@ class OpSequence:
         if rc != 0:
             _lib.check(rc, f"sqllm_launch_sequence (op {self._done.value} of {self.n})")
 
+    def profile(self, reps: int = 3):
+        """Per-op kernel durations in microseconds (device-side begin->end of each dispatch, as a
+        profiler would report them), averaged over `reps` passes.  Synchronises."""
+        import numpy as np
+
+        out = (ctypes.c_float * self.n)()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.sqllm_profile_sequence(self.ops, self.n, stream, int(reps), out)
+        _lib.check(rc, "sqllm_profile_sequence")
+        return np.ctypeslib.as_array(out).astype(np.float64).copy()
+
     def graph(self, warmup: int = 1) -> "torch.cuda.CUDAGraph":
         """Capture one pass into a HIP graph (replay with .replay())."""
         side = torch.cuda.Stream(self.device)
