@@ -1,0 +1,162 @@
+"""CPU tests of the drop-in boundary (no GPU, no compute calls): the C-ABI library loads, exports
+every symbol include/sqllm_hip.h declares, plans launches, rejects bad arguments before touching
+the device, and the Python operator module refuses CPU tensors instead of falling back."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+HEADER = os.path.join(H.ROOT, "include", "sqllm_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sqllm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from squeezellm_amd import _lib
+
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 22
+    for name in syms:
+        assert hasattr(lib, name), f"{name} declared in sqllm_hip.h but not exported"
+    assert set(syms) == set(_lib.SIGNATURES), "ctypes prototypes out of sync with the header"
+    assert lib.sqllm_abi_version() == 1
+    # the 12 reference names (quant_cuda.cpp:257-270) + the 2 balanced ones
+    for b in (3, 4):
+        for kind in ("", "_spmv", "_spmv_hybrid"):
+            for sfx in ("", "_batched"):
+                assert f"sqllm_vecquant{b}matmul{kind}_nuq_perchannel{sfx}" in syms
+        assert f"sqllm_vecquant{b}matmul_spmv_balanced_nuq_perchannel" in syms
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    c = tmp_path / "t.c"
+    c.write_text('#include "sqllm_hip.h"\nint main(void){ sqllm_op op; (void)op; return SQLLM_ABI_VERSION - 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{os.path.dirname(HEADER)}", str(c), "-o", str(tmp_path / "t")], check=True)
+    assert subprocess.run([str(tmp_path / "t")]).returncode == 0
+
+
+def test_python_operator_module_mirrors_reference_names():
+    import quant_cuda  # the top-level shim squeezellm/quant.py imports
+    from squeezellm_amd import quant_cuda as impl
+
+    names = [f"vecquant{b}matmul{k}_nuq_perchannel{s}" for b in (3, 4) for k in ("", "_spmv", "_spmv_hybrid") for s in ("", "_batched")]
+    names += [f"vecquant{b}matmul_spmv_balanced_nuq_perchannel" for b in (3, 4)]
+    for n in names:
+        assert callable(getattr(quant_cuda, n)) and getattr(quant_cuda, n) is getattr(impl, n)
+    assert sorted(impl.__all__) == sorted(names)
+
+
+def test_plan_geometry():
+    from squeezellm_amd import _lib
+
+    _lib.set_option("cu_count", 256)
+    p = _lib.plan_query(4, 4096, 4096)
+    assert p["col_tiles"] == 64 and p["dense_blocks"] == p["col_tiles"] * p["k_slices"]
+    assert p["csr_blocks"] == 0 and p["topx_blocks"] == 0 and p["grid_y"] == 1
+    assert p["groups_per_wave"] % 32 == 0  # a K slice is whole workgroup steps (8 waves x 4 units)
+    # every unit is covered exactly once
+    assert p["k_slices"] * p["groups_per_wave"] >= 4096 // 8 > (p["k_slices"] - 1) * p["groups_per_wave"]
+    p3 = _lib.plan_query(3, 11008, 4096, nnz=202_899, topX=10)
+    assert p3["csr_blocks"] == -(-202_899 // 1024) and p3["topx_blocks"] == 11008 // 128
+    assert p3["grid_x"] >= p3["dense_blocks"] + p3["csr_blocks"] + p3["topx_blocks"]
+    assert (p3["grid_x"] - p3["dense_blocks"]) % 8 == 0  # dense ids stay XCD-aligned
+    assert _lib.plan_query(4, 4096, 4096, batch=9)["grid_y"] == 2  # batch tiles of 8
+    assert _lib.plan_query(4, 4096, 4096, batch=3)["grid_y"] == 1
+    # options round-trip and steer the plan
+    _lib.set_option("target_wgs", 1024)
+    assert _lib.get_option("target_wgs") == 1024
+    assert _lib.plan_query(4, 4096, 4096)["dense_blocks"] == 1024
+    _lib.set_option("target_wgs", 0)
+    with pytest.raises(ValueError):
+        _lib.set_option("no_such_option", 1)
+    with pytest.raises(ValueError):
+        _lib.plan_query(5, 4096, 4096)
+    with pytest.raises(ValueError):
+        _lib.plan_query(4, 4100, 4096)  # K % 32
+    with pytest.raises(ValueError):
+        _lib.plan_query(4, 4096, 4098)  # N % 4
+
+
+def test_launch_rejects_bad_arguments_before_touching_the_device():
+    from squeezellm_amd import _lib
+
+    lib = _lib.load()
+    op = _lib.SqllmOp(bits=4, batch=0, K=128, N=128)
+    assert lib.sqllm_launch(ctypes.byref(op), None) == -3  # SQLLM_E_NULL: no operand pointers
+    op.vec = op.qweight = op.mul = op.lookup_table = 16
+    op.bits = 5
+    assert lib.sqllm_launch(ctypes.byref(op), None) == -1  # SQLLM_E_BITS
+    op.bits, op.K = 4, 100
+    assert lib.sqllm_launch(ctypes.byref(op), None) == -2  # SQLLM_E_SHAPE
+    op.K, op.qweight = 128, 20
+    assert lib.sqllm_launch(ctypes.byref(op), None) == -4  # SQLLM_E_ALIGN
+    op.qweight, op.batch = 16, -1
+    assert lib.sqllm_launch(ctypes.byref(op), None) == -6  # SQLLM_E_BATCH
+    # named entry points: height must be K/32*bits, num_rows must equal N
+    f = lib.sqllm_vecquant3matmul_nuq_perchannel
+    assert f(16, 16, 16, 16, 16, 128, None) == -2  # 16 rows is not a multiple of 3
+    g = lib.sqllm_vecquant4matmul_spmv_nuq_perchannel
+    assert g(16, 16, 16, 16, 16, 64, 16, 16, 16, 128, 10, None) == -5  # num_rows != width
+    assert lib.sqllm_vecquant4matmul_nuq_perchannel_batched(16, 16, 16, 16, 16, 128, 0, 128, None) == -6
+    assert lib.sqllm_vecquant4matmul_nuq_perchannel_batched(16, 16, 16, 16, 16, 128, 2, 64, None) == -6
+    assert b"bits" in lib.sqllm_error_string(-1) and lib.sqllm_error_string(0) == b"ok"
+    n_done = ctypes.c_int32(-1)
+    assert lib.sqllm_launch_sequence(None, 0, None, ctypes.byref(n_done)) == 0 and n_done.value == 0
+
+
+def test_no_cpu_fallback_in_the_operator_module():
+    import torch
+
+    from squeezellm_amd import quant_cuda as qc
+
+    case = H.make_case(4, 128, 128, seed=0)
+    t = H.to_torch(case, "cpu")
+    x, y = torch.randn(128), torch.zeros(128)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        qc.vecquant4matmul_nuq_perchannel(x, t["qweight"], y, t["lookup_table"])
+    with pytest.raises(TypeError):
+        qc.vecquant4matmul_nuq_perchannel(x.double(), t["qweight"], y, t["lookup_table"])
+    with pytest.raises(ValueError):
+        qc.vecquant4matmul_nuq_perchannel(x, t["qweight"][:, :64], y, t["lookup_table"])
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under squeezellm_amd/ (nor the quant_cuda shim)
+    may import or reference it."""
+    pkg = os.path.join(H.ROOT, "squeezellm_amd")
+    files = [os.path.join(dp, f) for dp, _, fs in os.walk(pkg) for f in fs if f.endswith((".py", ".hip", ".h"))]
+    files.append(os.path.join(H.ROOT, "quant_cuda.py"))
+    for f in files:
+        src = open(f).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+        assert "sqllm_oracle" not in src and "libsqllm_ref" not in src, f
+
+
+def test_quantlinear_module_schema_matches_reference():
+    import torch
+
+    from squeezellm_amd.quant import QuantLinearLUT
+
+    m = QuantLinearLUT(3, 256, 128, True, include_sparse=True, numvals=77, topX=10, balanced=True)
+    sd = m.state_dict()
+    assert sd["qweight"].shape == (256 // 32 * 3, 128) and sd["qweight"].dtype == torch.int32
+    assert sd["lookup_table"].shape == (128, 8) and sd["bias"].shape == (128,)
+    assert sd["rows"].shape == (129,) and sd["cols"].shape == (77,) and sd["vals"].dtype == torch.float32
+    assert sd["full_rows"].shape == (256, 10) and sd["full_row_indices"].dtype == torch.int32
+    assert sd["startrows"].shape == (128,)  # ceil(77/10) -> 8 -> rounded up to 128 threads
+    assert m.op_kind(False) == "spmv_hybrid" and QuantLinearLUT(4, 64, 64, False).op_kind(True) == "dense"
+    assert QuantLinearLUT(4, 64, 64, False, include_sparse=True, numvals=3, balanced=True).op_kind(False) == "spmv_balanced"
+    assert QuantLinearLUT(4, 64, 64, False, include_sparse=True, numvals=3, balanced=True).op_kind(True) == "spmv"
+    with pytest.raises(NotImplementedError):
+        QuantLinearLUT(2, 64, 64, False)

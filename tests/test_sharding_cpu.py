@@ -1,0 +1,111 @@
+"""The N > 1 path on CPU: world_size-2 gloo processes run the layer-sharded ring pipeline
+(squeezellm_amd/sharding.py) with an injected CPU stage and must reproduce the single-process
+result; plus the layer partition arithmetic."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from squeezellm_amd import sharding
+from tests import helpers as H
+
+
+def test_partition_layers():
+    assert sharding.partition_layers(32, 8) == [(4 * i, 4 * i + 4) for i in range(8)]
+    assert sharding.partition_layers(80, 8)[0] == (0, 10)
+    p = sharding.partition_layers(10, 4)
+    assert p == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert sharding.partition_layers(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    with pytest.raises(ValueError):
+        sharding.partition_layers(4, 0)
+    for L in range(0, 40):
+        for W in range(1, 9):
+            parts = sharding.partition_layers(L, W)
+            assert parts[0][0] == 0 and parts[-1][1] == L
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+HIDDEN, LAYERS, TICKS = 64, 4, 8
+
+
+def _make_layers():
+    """A tiny 'decoder stack': LAYERS square quantised linears with bias-free hybrid operands."""
+    return [H.make_case(4 if i % 2 else 3, HIDDEN, HIDDEN, sparse=0.05, topX=2, seed=100 + i) for i in range(LAYERS)]
+
+
+def _stage_fn(layers):
+    """CPU stage: the oracle stands in for the GPU kernels (test double), then an RMS-norm so values
+    stay O(1) around the ring, like sharding.DecodeStage."""
+    def fn(h):
+        v = h.double().numpy()
+        for lay in layers:
+            v = H.oracle_ref(lay, v.astype(np.float32), np.zeros(HIDDEN, np.float32), "hybrid")
+            v = v / np.sqrt((v * v).mean() + 1e-6)
+        return torch.from_numpy(v).to(h.dtype)
+    return fn
+
+
+def _h0(r):
+    return torch.from_numpy(np.random.default_rng(500 + r).normal(size=HIDDEN)).float()
+
+
+def _reference_ring(world):
+    """Single-process emulation of the ring schedule for `world` stages."""
+    layers = _make_layers()
+    parts = sharding.partition_layers(LAYERS, world)
+    stages = [_stage_fn(layers[a:b]) for a, b in parts]
+    h_in = [_h0(r) for r in range(world)]
+    outs = None
+    for _ in range(TICKS):
+        outs = [stages[r](h_in[r]) for r in range(world)]
+        h_in = [outs[(r - 1) % world] for r in range(world)]
+    return torch.stack(outs)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    layers = _make_layers()
+    a, b = sharding.partition_layers(LAYERS, world)[rank]
+    pipe = sharding.RingPipeline(_stage_fn(layers[a:b]), HIDDEN, rank=rank, world_size=world, device="cpu",
+                                 dtype=torch.float32, h0=_h0(rank))
+    out = None
+    for _ in range(TICKS):
+        out = pipe.tick()
+    q.put((rank, out.numpy(), pipe.buf.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_ring_pipeline_gloo_matches_single_process(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = _reference_ring(world).numpy()
+    for rank, out, buf in res:
+        assert np.allclose(out, want[rank], rtol=1e-5, atol=1e-6)
+        assert np.allclose(buf, want, rtol=1e-5, atol=1e-6)  # everyone gathered everyone's output
+
+
+def test_ring_pipeline_world1_is_a_plain_loop():
+    layers = _make_layers()
+    pipe = sharding.RingPipeline(_stage_fn(layers), HIDDEN, rank=0, world_size=1, device="cpu", dtype=torch.float32, h0=_h0(0))
+    pipe.run(3)
+    h = _h0(0)
+    f = _stage_fn(layers)
+    for _ in range(3):
+        h = f(h)
+    assert torch.allclose(pipe.h_in, h)
