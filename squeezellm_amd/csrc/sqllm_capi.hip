@@ -76,10 +76,10 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm) {
   if (upw <= 0) {
     int target = g_target_wgs.load(std::memory_order_relaxed);
     if (target <= 0) {
-      // measured on MI355X (tools/sweep.py): layers under ~12 MB of packed weights run best with one
-      // 8-wave workgroup per CU, larger ones with ~2.5 per CU
+      // measured on MI355X (tools/sweep.py, bench.py): layers under ~12 MB of packed weights run
+      // best with one 8-wave workgroup per CU, larger ones with ~3 per CU
       const double mb = (double)op->K * op->N * op->bits / 8.0 / 1e6;
-      target = mb <= 12.0 ? cu_count() : cu_count() * 5 / 2;
+      target = mb <= 12.0 ? cu_count() : 3 * cu_count();
     }
     int slices = (target + gm->col_tiles / 2) / gm->col_tiles;
     if (slices < 1) slices = 1;

@@ -337,13 +337,33 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
   };
 
   // ---- codebook loads, then the first chunk's loads, go out before anything is waited for.
-  //      Thread t fetches float4 #t of the tile's contiguous codebook block.
-  constexpr int LUT_F4 = kTileN * L / 4;
-  f32x4 e = {0.f, 0.f, 0.f, 0.f};
+  // Staging is organised by LDS ROW (64 dwords = 256 B): a wave writes whole rows with lane ==
+  // position in the row, so the writes of a half-wave hit 32 different banks.  (Letting thread t
+  // write "its" float4 of the codebook block put 32 consecutive threads on 2 banks: 16-way
+  // conflicts, measured as SQ_LDS_BANK_CONFLICT ~ SQ_ACTIVE_INST_LDS and 1-2 us per launch.)
+  //   4-bit: row = (column j, entry idx), 64 slots = 4 copies x 16 column groups;
+  //          wave w stages column j = w % 4, entries [(w / 4) * EPW, + EPW), EPW = 64 / WAVES.
+  //   3-bit: row = (column j, entry pair), 2 entries x 32 slots (2 copies x 16 column groups);
+  //          wave w stages column j = w % 4, pairs [(w / 4) * RPW, + RPW), RPW = 16 / WAVES.
+  constexpr int EPW = 64 / WAVES;                       // 4-bit: entries per wave
+  constexpr int RPW = 16 / WAVES;                       // 3-bit: entry pairs per wave
+  constexpr int NE = (BITS == 4) ? EPW : RPW;           // codebook values this thread stages
+  float ev[NE];
+  const int st_j = wave & 3, st_h = wave >> 2;
   if constexpr (!(ABL & 4)) {
-    int c = col0 + (tid % LUT_F4) / (L / 4);
+    int c = col0 + 4 * i16 + st_j;  // the column whose entries this lane stages
     if (c > N - 1) c = N - 1;
-    e = *reinterpret_cast<const f32x4*>(lut + (size_t)c * L + (tid % (L / 4)) * 4);
+    const float* src = lut + (size_t)c * L;
+    if constexpr (BITS == 4) {
+#pragma unroll
+      for (int v4 = 0; v4 < EPW / 4; ++v4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + st_h * EPW + 4 * v4);
+        ev[4 * v4 + 0] = t.x; ev[4 * v4 + 1] = t.y; ev[4 * v4 + 2] = t.z; ev[4 * v4 + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) ev[i] = src[2 * (st_h * RPW + i) + (lane >> 5)];
+    }
   }
   u32x4 w0[NBUF][R];
   float x0[NXR][BT];
@@ -352,16 +372,17 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- stage the codebooks: float4 #t = 4 entries of column t / (L/4); all copies ----
+  // ---- stage the codebooks (row-wise, see above) ----
   if constexpr (!(ABL & 4)) {
-    if (tid < LUT_F4) {
-      const int c = tid / (L / 4), e0 = (tid % (L / 4)) * 4;
-      float* dst = lds + ((c & 3) * SUBB + e0 * ESTRIDE) / 4 + (c >> 2);
-      const float ev[4] = {e.x, e.y, e.z, e.w};
+    if constexpr (BITS == 4) {
+      float* dst = lds + (st_j * SUBB + st_h * EPW * ESTRIDE) / 4 + lane;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < EPW; ++i) dst[i * (ESTRIDE / 4)] = ev[i];
+    } else {
+      // entry idx = 2 * pair + (lane >> 5); slot = lane & 31
+      float* dst = lds + (st_j * SUBB) / 4 + (lane >> 5) * (ESTRIDE / 4) + (lane & 31);
 #pragma unroll
-        for (int cp = 0; cp < COPIES; ++cp) dst[i * (ESTRIDE / 4) + 16 * cp] = ev[i];
+      for (int i = 0; i < RPW; ++i) dst[2 * (st_h * RPW + i) * (ESTRIDE / 4)] = ev[i];
     }
   }
 

@@ -43,19 +43,25 @@ def main():
         n += 1
         if n >= args.top:
             break
-    # PMC counters, if the run collected any
+    # PMC counters, if the run collected any (view pmc_events: one row per dispatch x counter)
     try:
+        key2 = "k.name, k.grid_x, p.counter_name" if args.by_grid else "k.name, p.counter_name"
         pm = list(cur.execute(
-            "select k.name, p.counter_name, count(*), sum(p.value) from pmc_events p join kernels k on p.dispatch_id = k.dispatch_id "
-            "group by k.name, p.counter_name order by k.name"))
-    except sqlite3.Error:
+            f"select {key2}, count(*), sum(p.counter_value), avg(k.duration) from pmc_events p "
+            f"join kernels k on p.dispatch_id = k.dispatch_id group by {key2} order by k.name"))
+    except sqlite3.Error as exc:
         pm = []
+        print("no PMC data:", exc)
     if pm:
-        print("\nPMC counters (sum over dispatches / dispatches):")
-        for name, cname, cnt, val in pm:
+        print("\nPMC counters per dispatch (mean over dispatches):")
+        for row in pm:
+            if args.by_grid:
+                name, grid, cname, cnt, val, dur = row
+            else:
+                (name, cname, cnt, val, dur), grid = row, ""
             if args.match and args.match not in name:
                 continue
-            print(f"  {short(name):<70} {cname:<24} n={cnt:<6} per-dispatch={val / cnt:,.1f}")
+            print(f"  {short(name):<60} grid={str(grid):<8} {cname:<22} n={cnt:<6} mean={val / cnt:>16,.1f}  mean_dur_us={dur / 1e3:.3f}")
 
 
 if __name__ == "__main__":
