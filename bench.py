@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--layers", type=int, default=None, help="decoder layers to build (default: the model's)")
     ap.add_argument("--launch", default="graph", choices=["graph", "sequence"],
                     help="timed region: HIP-graph replay of the pass, or one C call enqueuing it eagerly")
+    ap.add_argument("--no-fuse", action="store_true",
+                    help="one launch per linear (224 per token for 7B) instead of fusing the linears of a decoder "
+                         "layer that read the same input (q/k/v, gate/up) into one launch each")
     ap.add_argument("--parallel", default="auto", choices=["auto", "replicas", "pipeline"],
                     help="N > 1: independent replicas (weak scaling) or layer-sharded ring pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -156,9 +159,20 @@ def main():
 
     if mode == "replicas":
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
-        xs = [torch.randn(l["K"], device=dev, generator=g, dtype=torch.float16).float() for l in layers]
+        # activations as in the decoder layer: q/k/v read the same hidden state, gate/up the same
+        # post-attention state, o_proj and down_proj their own inputs (model_parse.py:53-61)
+        shared = {"k_proj": "q_proj", "v_proj": "q_proj", "up_proj": "gate_proj"}
+        xs, last = [], {}
+        for l in layers:
+            lname = l["name"].rsplit(".", 1)[1]
+            src = shared.get(lname)
+            if src is not None and src in last:
+                xs.append(last[src])
+            else:
+                xs.append(torch.randn(l["K"], device=dev, generator=g, dtype=torch.float16).float())
+            last[lname] = xs[-1]
         ys = [torch.zeros(l["N"], device=dev, dtype=torch.float32) for l in layers]
-        seq = decode.OpSequence(layers, xs, ys)
+        seq = decode.OpSequence(layers, xs, ys, fuse_shared_input=not args.no_fuse)
         if args.launch == "graph":
             graph = seq.graph(warmup=1)
             step = graph.replay
@@ -215,7 +229,10 @@ def main():
             "workload": f"{cfg['model']} w{cfg['bits']} " + (f"s{int(round(cfg['sparse'] * 10000))} (0.45% CSR outliers + top-{cfg['topX']} rows)" if cfg["sparse"] else "s0 (dense-only)")
                         + f", batch=1 decode, {model_layers} layers x {per_layer} linears, op {cfg['op']}",
             "config_name": args.config,
-            "launch": args.launch if mode == "replicas" else "sequence + ring all-gather",
+            "launch": (args.launch + (", one launch per linear" if args.no_fuse else
+                                      ", linears sharing an input (q/k/v, gate/up) fused into one launch each"))
+            if mode == "replicas" else "sequence + ring all-gather",
+            "launches_per_token": seq.n_groups if mode == "replicas" else None,
             "parallelism": "single GPU" if world == 1 else (
                 f"dp{world}: independent token streams, one full model replica per GPU, no data-path collective"
                 if mode == "replicas" else
@@ -232,9 +249,10 @@ def main():
             import numpy as np
 
             seq.profile(reps=1)  # warm
-            us = seq.profile(reps=5)
+            us = seq.profile(reps=5)  # one entry per launch (= per group of fused linears)
             avg_us = float(us.mean())
-            achieved = pass_bytes / len(layers) / (avg_us * 1e-6) / 1e9
+            n_launch = seq.n_groups
+            achieved = pass_bytes / n_launch / (avg_us * 1e-6) / 1e9
             result["roofline"] = {
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
@@ -244,15 +262,15 @@ def main():
                 "traffic": None,  # PMC FETCH_SIZE/WRITE_SIZE come from separate rocprofv3 --pmc runs (profiles/)
                 "kernel": f"sqllm_fused_matvec<{cfg['bits']},1>",
                 "avg_kernel_us": round(avg_us, 3),
-                "launches_per_step": len(layers),
-                "algorithmic_bytes_per_launch": int(pass_bytes / len(layers)),
+                "launches_per_step": n_launch,
+                "algorithmic_bytes_per_launch": int(pass_bytes / n_launch),
                 "sum_kernel_ms_per_step": round(float(us.sum()) * 1e-3, 4),
             }
             # per-layer matvec microseconds by shape (the other half of BASELINE.json's metric)
             table = {}
-            for l, u, b in zip(layers, us, bytes_per_op):
-                key = f"{l['K']}x{l['N']}"
-                table.setdefault(key, []).append((u, b))
+            for grp, u in zip(seq.groups, us):
+                key = "+".join(f"{layers[i]['K']}x{layers[i]['N']}" for i in grp)
+                table.setdefault(key, []).append((u, sum(bytes_per_op[i] for i in grp)))
             per_shape = {}
             for key, lst in table.items():
                 u = np.array([a for a, _ in lst])

@@ -44,6 +44,7 @@ extern "C" {
 #define SQLLM_E_SPARSE (-5)    /* inconsistent sparse operands (nnz < 0, num_rows != N, topX < 0) */
 #define SQLLM_E_BATCH (-6)     /* batch < 1 or vec_height != K for a batched op */
 #define SQLLM_E_OPTION (-7)    /* unknown option name / bad value */
+#define SQLLM_E_GROUP (-8)     /* group of 0 or > 4 ops, or members differ in vec / K / bits / batch */
 
 typedef void* sqllm_stream_t; /* a hipStream_t */
 
@@ -78,6 +79,18 @@ int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream);
  * returns it; *n_done (may be NULL) receives the number of ops enqueued. */
 int sqllm_launch_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t stream, int32_t* n_done);
 
+/* Same-input fusion: ONE kernel for 1..4 ops that read the same `vec` (same K, bits and batch) --
+ * in a decoder layer q_proj/k_proj/v_proj, and gate_proj/up_proj (squeezellm/model_parse.py:53-61).
+ * Every op keeps its own qweight / lookup_table / mul / sparse operands; the launch's workgroups
+ * are simply divided between them.  Halves the launch count of a LLaMA decode pass, which matters
+ * because each launch carries ~2-3 us of fixed cost against 1-4 us of streaming. */
+int sqllm_launch_group(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t stream);
+
+/* A whole pass as consecutive groups: group g covers the next group_sizes[g] entries of `ops`.
+ * *n_done (may be NULL) receives the number of groups enqueued. */
+int sqllm_launch_groups(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups,
+                        sqllm_stream_t stream, int32_t* n_done);
+
 /* Measurement aid (used by bench.py's roofline leg, never on the serving path): enqueue the ops like
  * sqllm_launch_sequence, but attach a start/stop event pair to EVERY kernel dispatch
  * (hipExtLaunchKernelGGL), so that each kernel's own device-side duration -- the quantity
@@ -86,6 +99,9 @@ int sqllm_launch_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t str
  * avg_us[0..n_ops).  Blocks the host; not graph-capturable. */
 int sqllm_profile_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t stream, int32_t reps,
                            float* avg_us);
+/* the same for grouped launches: avg_us[0..n_groups) */
+int sqllm_profile_groups(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups,
+                         sqllm_stream_t stream, int32_t reps, float* avg_us);
 
 /* ---------------------------------------------------------------------------------------------
  * The reference operator names.
@@ -188,8 +204,11 @@ int sqllm_abi_version(void);
 const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hipError_t values */
 
 /* Launch-geometry knobs (for measurement sweeps; defaults are chosen per shape):
- *   "target_wgs"      dense workgroups to aim for (default 0 = 2 x CU count)
- *   "groups_per_wave" force the K-groups each wave walks (default 0 = derived from target_wgs)
+ *   "target_wgs"      dense workgroups to aim for (default 0 = 1 x CU count for layers <= 12 MB,
+ *                     3 x CU count above)
+ *   "groups_per_wave" force the K units each wave walks (default 0 = derived from target_wgs)
+ *   "sparse_last"     1 = CSR / top-X workgroups after the dense ones in the grid (default 0)
+ *   "cu_count"        override the CU count used for planning (GPU-less tests)
  * Returns SQLLM_E_OPTION for an unknown name. */
 int sqllm_set_option(const char* name, int value);
 int sqllm_get_option(const char* name, int* value);

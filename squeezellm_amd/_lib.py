@@ -57,6 +57,9 @@ SIGNATURES = {
     "sqllm_launch": [POINTER(SqllmOp), P],
     "sqllm_launch_sequence": [POINTER(SqllmOp), c_int32, P, POINTER(c_int32)],
     "sqllm_profile_sequence": [POINTER(SqllmOp), c_int32, P, c_int32, POINTER(ctypes.c_float)],
+    "sqllm_launch_group": [POINTER(SqllmOp), c_int32, P],
+    "sqllm_launch_groups": [POINTER(SqllmOp), POINTER(c_int32), c_int32, P, POINTER(c_int32)],
+    "sqllm_profile_groups": [POINTER(SqllmOp), POINTER(c_int32), c_int32, P, c_int32, POINTER(ctypes.c_float)],
     "sqllm_abi_version": [],
     "sqllm_error_string": [c_int],
     "sqllm_set_option": [c_char_p, c_int],

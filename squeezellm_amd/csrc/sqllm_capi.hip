@@ -13,13 +13,10 @@
 
 namespace {
 
-constexpr int kDefaultWaves = 8;
 std::atomic<int> g_target_wgs{0};
 std::atomic<int> g_groups_per_wave{0};
 std::atomic<int> g_cu_count{0};
 std::atomic<int> g_ablate{0};
-std::atomic<int> g_variant{0};
-std::atomic<int> g_waves{0};
 std::atomic<int> g_sparse_last{0};
 
 int cu_count() {
@@ -68,11 +65,8 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm) {
   gm->batch = op->batch <= 0 ? 1 : op->batch;
   gm->col_tiles = (op->N + sqllm::kTileN - 1) / sqllm::kTileN;
   gm->units_total = op->K / kK;
-  int waves = g_waves.load(std::memory_order_relaxed);
-  if (waves != 4 && waves != 8 && waves != 16) waves = kDefaultWaves;
-  gm->waves = waves;
-  const int step = waves * 4;  // units one workgroup step covers
-  int upw = g_groups_per_wave.load(std::memory_order_relaxed) * waves;
+  const int step = sqllm::kWaves * 4;  // units one workgroup step covers
+  int upw = g_groups_per_wave.load(std::memory_order_relaxed) * sqllm::kWaves;
   if (upw <= 0) {
     int target = g_target_wgs.load(std::memory_order_relaxed);
     if (target <= 0) {
@@ -115,6 +109,7 @@ const char* sqllm_error_string(int code) {
     case SQLLM_E_SPARSE: return "inconsistent sparse operands";
     case SQLLM_E_BATCH: return "bad batch / vec_height";
     case SQLLM_E_OPTION: return "unknown option or bad value";
+    case SQLLM_E_GROUP: return "ops of a group must share vec, K, bits and batch (1..4 ops per group)";
     default: break;
   }
   if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
@@ -125,16 +120,10 @@ int sqllm_set_option(const char* name, int value) {
   if (!name || value < 0) return SQLLM_E_OPTION;
   if (!strcmp(name, "target_wgs")) { g_target_wgs.store(value); return SQLLM_OK; }
   if (!strcmp(name, "groups_per_wave")) { g_groups_per_wave.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "waves")) {
-    if (value != 0 && value != 4 && value != 8 && value != 16) return SQLLM_E_OPTION;
-    g_waves.store(value);
-    return SQLLM_OK;
-  }
   if (!strcmp(name, "sparse_last")) { g_sparse_last.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { g_cu_count.store(value); return SQLLM_OK; }  // for GPU-less planning tests
 #ifdef SQLLM_ABLATION_BUILD
   if (!strcmp(name, "ablate")) { g_ablate.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "variant")) { g_variant.store(value); return SQLLM_OK; }
 #endif
   return SQLLM_E_OPTION;
 }
@@ -143,7 +132,6 @@ int sqllm_get_option(const char* name, int* value) {
   if (!name || !value) return SQLLM_E_OPTION;
   if (!strcmp(name, "target_wgs")) { *value = g_target_wgs.load(); return SQLLM_OK; }
   if (!strcmp(name, "groups_per_wave")) { *value = g_groups_per_wave.load(); return SQLLM_OK; }
-  if (!strcmp(name, "waves")) { *value = g_waves.load(); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { *value = g_cu_count.load(); return SQLLM_OK; }
   return SQLLM_E_OPTION;
 }
@@ -167,58 +155,64 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   return SQLLM_OK;
 }
 
-static int launch_with_events(const sqllm_op* op, sqllm_stream_t stream, hipEvent_t e0, hipEvent_t e1) {
-  int rc = validate(op);
-  if (rc != SQLLM_OK) return rc;
+// One kernel over 1..kMaxSegments ops that share vec, K, bits and batch.
+static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t stream, hipEvent_t e0,
+                                    hipEvent_t e1) {
+  if (n < 1 || n > sqllm::kMaxSegments) return SQLLM_E_GROUP;
+  if (!ops) return SQLLM_E_NULL;
   sqllm::LaunchArgs a;
   a.ev_start = e0;
   a.ev_stop = e1;
   a.ablate = g_ablate.load(std::memory_order_relaxed);
-  a.variant = g_variant.load(std::memory_order_relaxed);
-  a.x = op->vec;
-  a.q = reinterpret_cast<const uint32_t*>(op->qweight);
-  a.y = op->mul;
-  a.lut = op->lookup_table;
-  a.rows = op->rows;
-  a.cols = op->cols;
-  a.vals = op->vals;
-  a.full_rows = op->full_rows;
-  a.full_idx = op->full_row_indices;
-  make_plan(op, &a.gm);
-  return static_cast<int>(sqllm::launch_fused(op->bits, a, static_cast<hipStream_t>(stream)));
+  a.x = ops[0].vec;
+  a.ga.n_seg = n;
+  int block = 0;
+  for (int i = 0; i < n; ++i) {
+    const sqllm_op* op = &ops[i];
+    int rc = validate(op);
+    if (rc != SQLLM_OK) return rc;
+    if (op->vec != ops[0].vec || op->K != ops[0].K || op->bits != ops[0].bits ||
+        (op->batch <= 0 ? 1 : op->batch) != (ops[0].batch <= 0 ? 1 : ops[0].batch))
+      return SQLLM_E_GROUP;
+    sqllm::Segment& sg = a.ga.seg[i];
+    sg.q = reinterpret_cast<const uint32_t*>(op->qweight);
+    sg.y = op->mul;
+    sg.lut = op->lookup_table;
+    sg.rows = op->rows;
+    sg.cols = op->cols;
+    sg.vals = op->vals;
+    sg.full_rows = op->full_rows;
+    sg.full_idx = op->full_row_indices;
+    make_plan(op, &sg.gm);
+    a.ga.block0[i] = block;
+    // pad every segment to a multiple of 8 workgroups: dense ids keep their XCD alignment
+    block += (sg.gm.dense_block0 + sg.gm.dense_blocks + 7) / 8 * 8;
+  }
+  for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
+  for (int i = n; i < sqllm::kMaxSegments; ++i) memset(&a.ga.seg[i], 0, sizeof(sqllm::Segment));
+  return static_cast<int>(sqllm::launch_fused(ops[0].bits, a, static_cast<hipStream_t>(stream)));
 }
 
 int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream) {
-  return launch_with_events(op, stream, nullptr, nullptr);
+  return launch_group_with_events(op, 1, stream, nullptr, nullptr);
 }
 
-int sqllm_profile_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t stream, int32_t reps,
-                           float* avg_us) {
-  if (n_ops < 0 || reps < 1 || (n_ops > 0 && (!ops || !avg_us))) return SQLLM_E_NULL;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  hipEvent_t* ev = new hipEvent_t[2 * (size_t)n_ops];
-  int rc = SQLLM_OK;
-  int made = 0;
-  for (; made < 2 * n_ops; ++made)
-    if (hipEventCreate(&ev[made]) != hipSuccess) { rc = (int)hipGetLastError(); break; }
-  for (int i = 0; i < n_ops; ++i) avg_us[i] = 0.f;
-  for (int r = 0; r < reps && rc == SQLLM_OK; ++r) {
-    for (int i = 0; i < n_ops && rc == SQLLM_OK; ++i)
-      rc = launch_with_events(&ops[i], stream, ev[2 * i], ev[2 * i + 1]);
-    if (rc != SQLLM_OK) break;
-    hipError_t e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { rc = (int)e; break; }
-    for (int i = 0; i < n_ops; ++i) {
-      float ms = 0.f;
-      e = hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
-      if (e != hipSuccess) { rc = (int)e; break; }
-      avg_us[i] += ms * 1000.f;
-    }
+int sqllm_launch_group(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t stream) {
+  return launch_group_with_events(ops, n_ops, stream, nullptr, nullptr);
+}
+
+int sqllm_launch_groups(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups,
+                        sqllm_stream_t stream, int32_t* n_done) {
+  if (n_done) *n_done = 0;
+  if (n_groups < 0 || (n_groups > 0 && (!ops || !group_sizes))) return SQLLM_E_NULL;
+  int32_t at = 0;
+  for (int32_t g = 0; g < n_groups; ++g) {
+    int rc = launch_group_with_events(ops + at, group_sizes[g], stream, nullptr, nullptr);
+    if (rc != SQLLM_OK) return rc;
+    at += group_sizes[g];
+    if (n_done) *n_done = g + 1;
   }
-  for (int i = 0; i < n_ops; ++i) avg_us[i] /= (float)reps;
-  for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
-  delete[] ev;
-  return rc;
+  return SQLLM_OK;
 }
 
 int sqllm_launch_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t stream, int32_t* n_done) {
@@ -230,6 +224,48 @@ int sqllm_launch_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t str
     if (n_done) *n_done = i + 1;
   }
   return SQLLM_OK;
+}
+
+int sqllm_profile_groups(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups,
+                         sqllm_stream_t stream, int32_t reps, float* avg_us) {
+  if (n_groups < 0 || reps < 1 || (n_groups > 0 && (!ops || !group_sizes || !avg_us))) return SQLLM_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipEvent_t* ev = new hipEvent_t[2 * (size_t)n_groups + 1];
+  int rc = SQLLM_OK;
+  int made = 0;
+  for (; made < 2 * n_groups; ++made)
+    if (hipEventCreate(&ev[made]) != hipSuccess) { rc = (int)hipGetLastError(); break; }
+  for (int i = 0; i < n_groups; ++i) avg_us[i] = 0.f;
+  for (int r = 0; r < reps && rc == SQLLM_OK; ++r) {
+    int32_t at = 0;
+    for (int g = 0; g < n_groups && rc == SQLLM_OK; ++g) {
+      rc = launch_group_with_events(ops + at, group_sizes[g], stream, ev[2 * g], ev[2 * g + 1]);
+      at += group_sizes[g];
+    }
+    if (rc != SQLLM_OK) break;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { rc = (int)e; break; }
+    for (int g = 0; g < n_groups; ++g) {
+      float ms = 0.f;
+      e = hipEventElapsedTime(&ms, ev[2 * g], ev[2 * g + 1]);
+      if (e != hipSuccess) { rc = (int)e; break; }
+      avg_us[g] += ms * 1000.f;
+    }
+  }
+  for (int g = 0; g < n_groups; ++g) avg_us[g] /= (float)reps;
+  for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+  delete[] ev;
+  return rc;
+}
+
+int sqllm_profile_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t stream, int32_t reps,
+                           float* avg_us) {
+  if (n_ops < 0) return SQLLM_E_NULL;
+  int32_t* ones = new int32_t[n_ops > 0 ? n_ops : 1];
+  for (int32_t i = 0; i < n_ops; ++i) ones[i] = 1;
+  int rc = sqllm_profile_groups(ops, ones, n_ops, stream, reps, avg_us);
+  delete[] ones;
+  return rc;
 }
 
 // ---- the reference operator names -------------------------------------------------------------

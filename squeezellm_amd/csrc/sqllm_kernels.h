@@ -5,6 +5,7 @@
 
 namespace sqllm {
 
+constexpr int kWaves = 8;          // waves per workgroup (512 threads)
 constexpr int kTileN = 64;         // output columns per dense tile = 16 lanes x 4 (one dwordx4 each)
 constexpr int kCsrChunk = 1024;    // non-zeros per CSR workgroup
 constexpr int kCsrSpanMax = 2048;  // CSR rows a chunk may span and still accumulate in LDS
@@ -27,7 +28,6 @@ struct KernelGeom {
   int K, N, batch;
   int col_tiles;        // ceil(N / 64)
   int units_total;      // K / 8 (w4: qweight rows) or K / 32 (w3: three-row units)
-  int waves;            // waves per workgroup (4, 8 or 16): selects the kernel instantiation
   int units_per_wg;     // K-slice length of a workgroup, in units (a multiple of waves * 4)
   int k_slices;         // ceil(units_total / units_per_wg)
   int dense_blocks;     // col_tiles * k_slices
@@ -38,8 +38,10 @@ struct KernelGeom {
   int sparse_last;      // 1: CSR / top-X workgroups come after the dense ones in the grid
 };
 
-struct LaunchArgs {
-  const float* x;
+constexpr int kMaxSegments = 4;   // ops one launch can cover (they share vec, K, bits, batch)
+
+// One op of a launch: its operands and its geometry.
+struct Segment {
   const uint32_t* q;
   float* y;
   const float* lut;
@@ -49,10 +51,23 @@ struct LaunchArgs {
   const float* full_rows;
   const int* full_idx;
   KernelGeom gm;
+};
+
+// Kernel argument block: up to kMaxSegments ops over the same input vector.  Workgroup ids
+// [block0[s], block0[s+1]) belong to segment s (each range is a multiple of 8 long, so a dense
+// tile's id modulo 8 -- its XCD -- does not depend on the segments before it).
+struct GroupArgs {
+  int n_seg;
+  int block0[kMaxSegments + 1];
+  Segment seg[kMaxSegments];
+};
+
+struct LaunchArgs {
+  const float* x;
+  GroupArgs ga;
   hipEvent_t ev_start = nullptr;  // optional: recorded at this kernel's begin / end (profiling aid)
   hipEvent_t ev_stop = nullptr;
-  int ablate = 0;   // measurement builds only (SQLLM_ABLATION_BUILD)
-  int variant = 0;  // measurement builds only: waves * 10 + prefetch depth
+  int ablate = 0;  // measurement builds only (SQLLM_ABLATION_BUILD)
 };
 
 // batch rows handled per weight pass for a given batch size (template instantiations 1/2/4/8)

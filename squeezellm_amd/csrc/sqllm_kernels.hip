@@ -627,20 +627,25 @@ template <int BITS, int BT, int WAVES, int ABL = 0>
 // occupancy target: 2 workgroups of 8 waves per CU (<= 128 VGPRs); the 3-bit kernels with a wide
 // batch tile need more registers and settle for one workgroup per CU rather than spill
 __global__ void __launch_bounds__(WAVES * 64, (BITS == 3 && BT >= 4) ? 2 : 4)
-sqllm_fused_matvec(const float* x, const u32x4* q, float* __restrict__ y, const float* lut,
-                   const int* __restrict__ rows, const int* __restrict__ cols,
-                   const float* __restrict__ vals, const float* __restrict__ full_rows,
-                   const int* __restrict__ full_idx, KernelGeom gm) {
+sqllm_fused_matvec(const float* x, const GroupArgs ga) {
   constexpr int T = WAVES * 64;
   constexpr int CB = BT < 4 ? BT : 4;
   constexpr int kLds = lds_floats(Fmt<BITS>::kLut, WAVES, CB);
   __shared__ __attribute__((aligned(16))) float lds[kLds];
-  const int bid = blockIdx.x;
+
+  // which op of the launch this workgroup belongs to (wave-uniform; 1 segment = a plain op)
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxSegments; ++i)
+    if (i < ga.n_seg && (int)blockIdx.x >= ga.block0[i]) s = i;
+  const Segment& sg = ga.seg[s];
+  const KernelGeom& gm = sg.gm;
+  const int bid = blockIdx.x - ga.block0[s];
   const int b0 = blockIdx.y * BT;
   int nb = gm.batch - b0;
   if (nb > BT) nb = BT;
 
-  // role by block id: [sparse | pad | dense] or, with sparse_last, [dense | sparse]
+  // role by block id within the segment: [sparse | pad | dense] or, with sparse_last, [dense | sparse]
   int d, sp;
   if (gm.sparse_last) {
     d = bid;
@@ -650,12 +655,12 @@ sqllm_fused_matvec(const float* x, const u32x4* q, float* __restrict__ y, const 
     sp = bid < gm.dense_block0 ? bid : -1;
   }
   if (d >= 0 && d < gm.dense_blocks) {
-    dense_role<BITS, BT, WAVES, ABL>(x, q, y, lut, gm.K, gm.N, b0, nb, d, gm.col_tiles,
-                                     gm.units_total, gm.units_per_wg, lds);
+    dense_role<BITS, BT, WAVES, ABL>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, b0, nb,
+                                     d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds);
   } else if (sp >= 0 && sp < gm.csr_blocks) {
-    csr_role<T>(x, y, rows, cols, vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds);
+    csr_role<T>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds);
   } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
-    topx_role<T>(x, y, full_rows, full_idx, gm.topX, gm.K, gm.N, b0, nb, sp - gm.csr_blocks, lds);
+    topx_role<T>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, b0, nb, sp - gm.csr_blocks, lds);
   }
 }
 
@@ -711,8 +716,8 @@ __global__ void __launch_bounds__(256) sqllm_calib_tiled(const u32x4* q, int row
 }
 template <int SEGL>
 static void launch_tiled(const LaunchArgs& a, hipStream_t stream, int target_wgs) {
-  const int rows_total = a.gm.units_total * (a.gm.K / a.gm.units_total == 8 ? 1 : 3);
-  const int row_stride16 = a.gm.N / 4;
+  const int rows_total = a.ga.seg[0].gm.units_total * (a.ga.seg[0].gm.K / a.ga.seg[0].gm.units_total == 8 ? 1 : 3);
+  const int row_stride16 = a.ga.seg[0].gm.N / 4;
   const int col_tiles = (row_stride16 + SEGL - 1) / SEGL;
   int slices = (target_wgs + col_tiles - 1) / col_tiles;
   if (slices < 1) slices = 1;
@@ -721,7 +726,7 @@ static void launch_tiled(const LaunchArgs& a, hipStream_t stream, int target_wgs
   rows_per_wg = (rows_per_wg + gran - 1) / gran * gran;
   slices = (rows_total + rows_per_wg - 1) / rows_per_wg;
   hipExtLaunchKernelGGL((sqllm_calib_tiled<SEGL>), dim3(col_tiles * slices), dim3(256), 0, stream, a.ev_start, a.ev_stop, 0,
-                        reinterpret_cast<const u32x4*>(a.q), rows_total, row_stride16, col_tiles, rows_per_wg, a.y);
+                        reinterpret_cast<const u32x4*>(a.ga.seg[0].q), rows_total, row_stride16, col_tiles, rows_per_wg, a.ga.seg[0].y);
 }
 static hipError_t launch_calib(const LaunchArgs& a, hipStream_t stream) {
   if (a.ablate >= 200) {  // 2SW: S = log2(lanes per segment) - 3 (0..3 -> 8,16,32,64 lanes), W = target wgs / 256
@@ -732,66 +737,58 @@ static hipError_t launch_calib(const LaunchArgs& a, hipStream_t stream) {
     else launch_tiled<64>(a, stream, tw);
     return hipGetLastError();
   }
-  const size_t n16 = (size_t)a.gm.units_total * (a.gm.K / a.gm.units_total == 8 ? 1 : 3) * (a.gm.N / 4);
+  const size_t n16 = (size_t)a.ga.seg[0].gm.units_total * (a.ga.seg[0].gm.K / a.ga.seg[0].gm.units_total == 8 ? 1 : 3) * (a.ga.seg[0].gm.N / 4);
   const int mode = a.ablate;
   dim3 grid(mode == 100 ? 512 : (mode % 10 == 1 ? 512 : mode % 10 == 2 ? 1024 : mode % 10 == 3 ? 2048 : 4096));
-  if (mode == 100) hipExtLaunchKernelGGL(sqllm_calib_empty, grid, dim3(256), 0, stream, a.ev_start, a.ev_stop, 0, a.y);
-  else if (mode < 120) hipExtLaunchKernelGGL((sqllm_calib_stream<4, true>), grid, dim3(256), 0, stream, a.ev_start, a.ev_stop, 0, reinterpret_cast<const u32x4*>(a.q), n16, a.y);
-  else if (mode < 130) hipExtLaunchKernelGGL((sqllm_calib_stream<8, true>), grid, dim3(256), 0, stream, a.ev_start, a.ev_stop, 0, reinterpret_cast<const u32x4*>(a.q), n16, a.y);
-  else hipExtLaunchKernelGGL((sqllm_calib_stream<8, false>), grid, dim3(256), 0, stream, a.ev_start, a.ev_stop, 0, reinterpret_cast<const u32x4*>(a.q), n16, a.y);
+  if (mode == 100) hipExtLaunchKernelGGL(sqllm_calib_empty, grid, dim3(256), 0, stream, a.ev_start, a.ev_stop, 0, a.ga.seg[0].y);
+  else if (mode < 120) hipExtLaunchKernelGGL((sqllm_calib_stream<4, true>), grid, dim3(256), 0, stream, a.ev_start, a.ev_stop, 0, reinterpret_cast<const u32x4*>(a.ga.seg[0].q), n16, a.ga.seg[0].y);
+  else if (mode < 130) hipExtLaunchKernelGGL((sqllm_calib_stream<8, true>), grid, dim3(256), 0, stream, a.ev_start, a.ev_stop, 0, reinterpret_cast<const u32x4*>(a.ga.seg[0].q), n16, a.ga.seg[0].y);
+  else hipExtLaunchKernelGGL((sqllm_calib_stream<8, false>), grid, dim3(256), 0, stream, a.ev_start, a.ev_stop, 0, reinterpret_cast<const u32x4*>(a.ga.seg[0].q), n16, a.ga.seg[0].y);
   return hipGetLastError();
 }
 #endif
 
 template <int BITS, int BT, int WAVES, int ABL = 0>
 static hipError_t launch_inst(const LaunchArgs& a, hipStream_t stream) {
-  dim3 grid(a.gm.dense_block0 + a.gm.dense_blocks, (a.gm.batch + BT - 1) / BT);
+  const int batch = a.ga.seg[0].gm.batch;
+  dim3 grid(a.ga.block0[a.ga.n_seg], (batch + BT - 1) / BT);
   auto kern = sqllm_fused_matvec<BITS, BT, WAVES, ABL>;
   if (a.ev_start || a.ev_stop) {
     // same kernel, with the dispatch's own begin/end timestamps exposed through two events
-    hipExtLaunchKernelGGL(kern, grid, dim3(WAVES * 64), 0, stream, a.ev_start, a.ev_stop, 0, a.x,
-                          reinterpret_cast<const u32x4*>(a.q), a.y, a.lut, a.rows, a.cols, a.vals,
-                          a.full_rows, a.full_idx, a.gm);
+    hipExtLaunchKernelGGL(kern, grid, dim3(WAVES * 64), 0, stream, a.ev_start, a.ev_stop, 0, a.x, a.ga);
   } else {
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), 0, stream, a.x,
-                       reinterpret_cast<const u32x4*>(a.q), a.y, a.lut, a.rows, a.cols, a.vals,
-                       a.full_rows, a.full_idx, a.gm);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), 0, stream, a.x, a.ga);
   }
   return hipGetLastError();
 }
 
-template <int BITS, int WAVES>
+template <int BITS>
 static hipError_t launch_bt(const LaunchArgs& a, hipStream_t stream) {
-  switch (batch_tile(a.gm.batch)) {
-    case 1: return launch_inst<BITS, 1, WAVES>(a, stream);
-    case 2: return launch_inst<BITS, 2, WAVES>(a, stream);
-    case 4: return launch_inst<BITS, 4, WAVES>(a, stream);
-    default: return launch_inst<BITS, 8, WAVES>(a, stream);
+  switch (batch_tile(a.ga.seg[0].gm.batch)) {
+    case 1: return launch_inst<BITS, 1, kWaves>(a, stream);
+    case 2: return launch_inst<BITS, 2, kWaves>(a, stream);
+    case 4: return launch_inst<BITS, 4, kWaves>(a, stream);
+    default: return launch_inst<BITS, 8, kWaves>(a, stream);
   }
 }
 
 hipError_t launch_fused(int bits, const LaunchArgs& a, hipStream_t stream) {
 #ifdef SQLLM_ABLATION_BUILD
   if (a.ablate >= 100) return launch_calib(a, stream);
-  if (bits == 4 && batch_tile(a.gm.batch) == 1 && a.ablate) {
-    switch (a.gm.waves * 100 + a.ablate) {
-      case 801: return launch_inst<4, 1, 8, 1>(a, stream);
-      case 802: return launch_inst<4, 1, 8, 2>(a, stream);
-      case 804: return launch_inst<4, 1, 8, 4>(a, stream);
-      case 808: return launch_inst<4, 1, 8, 8>(a, stream);
-      case 813: return launch_inst<4, 1, 8, 13>(a, stream);
-      case 814: return launch_inst<4, 1, 8, 14>(a, stream);
-      case 830: return launch_inst<4, 1, 8, 30>(a, stream);
-      case 816: return launch_inst<4, 1, 8, 16>(a, stream);
+  if (bits == 4 && batch_tile(a.ga.seg[0].gm.batch) == 1 && a.ablate) {
+    switch (a.ablate) {
+      case 1: return launch_inst<4, 1, kWaves, 1>(a, stream);
+      case 2: return launch_inst<4, 1, kWaves, 2>(a, stream);
+      case 4: return launch_inst<4, 1, kWaves, 4>(a, stream);
+      case 8: return launch_inst<4, 1, kWaves, 8>(a, stream);
+      case 13: return launch_inst<4, 1, kWaves, 13>(a, stream);
+      case 14: return launch_inst<4, 1, kWaves, 14>(a, stream);
+      case 16: return launch_inst<4, 1, kWaves, 16>(a, stream);
       default: break;
     }
   }
 #endif
-  switch (a.gm.waves) {
-    case 4: return bits == 4 ? launch_bt<4, 4>(a, stream) : launch_bt<3, 4>(a, stream);
-    case 16: return bits == 4 ? launch_bt<4, 16>(a, stream) : launch_bt<3, 16>(a, stream);
-    default: return bits == 4 ? launch_bt<4, 8>(a, stream) : launch_bt<3, 8>(a, stream);
-  }
+  return bits == 4 ? launch_bt<4>(a, stream) : launch_bt<3>(a, stream);
 }
 
 }  // namespace sqllm

@@ -24,7 +24,10 @@ def _ptr(t):
 class OpSequence:
     """A fixed list of ops `ys[i] += layer_i(xs[i])` with all pointers resolved up front."""
 
-    def __init__(self, layers, xs, ys, batched: bool = False):
+    def __init__(self, layers, xs, ys, batched: bool = False, fuse_shared_input: bool = False):
+        """fuse_shared_input: consecutive ops that read the SAME x tensor (and agree in K, bits,
+        batch) are enqueued as one kernel (sqllm_launch_group), up to 4 per launch -- q/k/v and
+        gate/up of a decoder layer."""
         if not (len(layers) == len(xs) == len(ys)):
             raise ValueError("layers, xs, ys must have equal length")
         self.n = len(layers)
@@ -50,25 +53,39 @@ class OpSequence:
             if lay.get("full_rows") is not None:
                 o.full_rows, o.full_row_indices = _ptr(lay["full_rows"]), _ptr(lay["full_row_indices"])
                 o.topX = lay["full_rows"].shape[1]
+        # launch groups: lists of consecutive op indices sharing one input vector
+        self.groups = []
+        for i in range(self.n):
+            o = self.ops[i]
+            if fuse_shared_input and self.groups and len(self.groups[-1]) < 4:
+                p = self.ops[self.groups[-1][0]]
+                if (p.vec, p.K, p.bits, p.batch) == (o.vec, o.K, o.bits, o.batch):
+                    self.groups[-1].append(i)
+                    continue
+            self.groups.append([i])
+        self.n_groups = len(self.groups)
+        self._sizes = (ctypes.c_int32 * max(self.n_groups, 1))(*[len(g) for g in self.groups])
         self._lib = _lib.load()
         self._done = ctypes.c_int32(0)
 
     def launch(self) -> None:
-        """Enqueue all ops on the current stream of the sequence's device (one FFI crossing)."""
+        """Enqueue the whole pass on the current stream of the sequence's device (one FFI crossing)."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self._lib.sqllm_launch_sequence(self.ops, self.n, stream, ctypes.byref(self._done))
+        rc = self._lib.sqllm_launch_groups(self.ops, self._sizes, self.n_groups, stream, ctypes.byref(self._done))
         if rc != 0:
-            _lib.check(rc, f"sqllm_launch_sequence (op {self._done.value} of {self.n})")
+            _lib.check(rc, f"sqllm_launch_groups (group {self._done.value} of {self.n_groups})")
 
     def profile(self, reps: int = 3):
-        """Per-op kernel durations in microseconds (device-side begin->end of each dispatch, as a
-        profiler would report them), averaged over `reps` passes.  Synchronises."""
+        """Per-LAUNCH kernel durations in microseconds (device-side begin->end of each dispatch, as
+        a profiler would report them), one per entry of `self.groups`, averaged over `reps`
+        passes.  Synchronises."""
         import numpy as np
 
-        out = (ctypes.c_float * self.n)()
+        out = (ctypes.c_float * max(self.n_groups, 1))()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self._lib.sqllm_profile_sequence(self.ops, self.n, stream, int(reps), out)
-        _lib.check(rc, "sqllm_profile_sequence")
+        rc = self._lib.sqllm_profile_groups(self.ops, self._sizes, self.n_groups, stream, int(reps), out)
+        _lib.check(rc, "sqllm_profile_groups")
+        out = (ctypes.c_float * self.n_groups).from_buffer(out)
         return np.ctypeslib.as_array(out).astype(np.float64).copy()
 
     def graph(self, warmup: int = 1) -> "torch.cuda.CUDAGraph":

@@ -139,3 +139,51 @@ def test_launch_is_on_the_current_stream_and_capturable(gpu):
     torch.cuda.synchronize()
     ref = H.oracle_ref(case, x.cpu().numpy(), np.zeros(512, np.float32), "dense")
     assert H.rel_err(y.cpu().numpy(), ref) <= 2e-5
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("batched", [False, True])
+def test_grouped_launch_same_input(gpu, bits, batched):
+    """Ops that share their input vector (q/k/v, gate/up) as ONE kernel: same results as separate
+    launches; mixed dense / sparse members; mismatching members are rejected."""
+    import ctypes
+
+    import torch
+
+    from squeezellm_amd import _lib, decode, synth
+
+    K = 1024
+    specs = [(384, 0.0, 0), (132, 0.01, 3), (1024, 0.0, 0), (64, 0.02, 0)]  # N, sparse, topX
+    layers = [synth.make_layer(K, N, bits, sparse_frac=sp, topX=tx, heavy_rows=1 if sp else 0, device=gpu, seed=10 + i)
+              for i, (N, sp, tx) in enumerate(specs)]
+    B = 5 if batched else 0
+    x = torch.randn((B, K) if batched else (K,), device=gpu)
+    other = synth.make_layer(512, 256, bits, device=gpu, seed=99)
+    x_other = torch.randn((B, 512) if batched else (512,), device=gpu)
+    all_layers = layers + [other]
+    xs = [x] * len(layers) + [x_other]
+
+    def run(fuse):
+        ys = [torch.zeros((B, l["N"]) if batched else (l["N"],), device=gpu) for l in all_layers]
+        seq = decode.OpSequence(all_layers, xs, ys, batched=batched, fuse_shared_input=fuse)
+        seq.launch()
+        torch.cuda.synchronize()
+        return seq, ys
+
+    seq1, y_sep = run(False)
+    seqf, y_fus = run(True)
+    assert seq1.n_groups == 5 and seqf.groups == [[0, 1, 2, 3], [4]]
+    for l, a, b in zip(all_layers, y_sep, y_fus):
+        npl = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in l.items()}
+        kind = "hybrid" if l["full_rows"] is not None else ("spmv" if l["vals"] is not None else "dense")
+        xin = (x_other if l is other else x).cpu().numpy()
+        ref = H.oracle_ref(npl, xin, np.zeros(tuple(a.shape), np.float32), kind)
+        assert H.rel_err(a.cpu().numpy(), ref) <= 2e-5
+        assert H.rel_err(b.cpu().numpy(), ref) <= 2e-5
+    us = seqf.profile(reps=1)
+    assert us.shape == (2,)
+    # a group whose members disagree is rejected before anything is enqueued
+    lib = _lib.load()
+    bad = (_lib.SqllmOp * 2)(seq1.ops[0], seq1.ops[4])
+    assert lib.sqllm_launch_group(bad, 2, None) == -8
+    assert lib.sqllm_launch_group(seq1.ops, 0, None) == -8 and lib.sqllm_launch_group(seq1.ops, 5, None) == -8

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--total-mb", type=float, default=700.0, help="distinct weight bytes to rotate over")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--sparse-last", type=int, default=0)
+    ap.add_argument("--group", type=int, default=1, help="ops per launch (sharing one input vector)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -39,25 +40,25 @@ def main():
     for shp in args.shapes.split(","):
         K, N = map(int, shp.split("x"))
         one = synth.algorithmic_bytes(K, N, args.bits)
-        copies = max(4, int(args.total_mb * 1e6 / one))
+        copies = max(4 * args.group, int(args.total_mb * 1e6 / one) // args.group * args.group)
         layers = [synth.make_layer(K, N, args.bits, sparse_frac=args.sparse, topX=args.topx,
                                    heavy_rows=10 if args.sparse > 0 else 0, device=dev, seed=i) for i in range(copies)]
         B = max(args.batch, 1)
-        xs = [torch.randn((B, K) if args.batch else (K,), device=dev) for _ in layers]
+        xs = []
+        for i in range(len(layers)):
+            xs.append(xs[-1] if i % args.group else torch.randn((B, K) if args.batch else (K,), device=dev))
         ys = [torch.zeros((B, N) if args.batch else (N,), device=dev) for _ in layers]
-        seq = decode.OpSequence(layers, xs, ys, batched=args.batch > 0)
-        nbytes = synth.layer_bytes(layers[0], B)
+        seq = decode.OpSequence(layers, xs, ys, batched=args.batch > 0, fuse_shared_input=args.group > 1)
+        nbytes = synth.layer_bytes(layers[0], B) * args.group
         for tw in map(int, args.target_wgs.split(",")):
-         for var in map(int, args.variant.split(",")):
-          if args.variant != "0":
-              _lib.set_option("variant", var)
+         for var in [0]:
           for abl in map(int, args.ablate.split(",")):
             for gpw in map(int, args.gpw.split(",")):
                 if abl or args.ablate != "0":
                     _lib.set_option("ablate", abl)
                 _lib.set_option("target_wgs", tw)
                 _lib.set_option("groups_per_wave", gpw)
-                seq2 = decode.OpSequence(layers, xs, ys, batched=args.batch > 0)
+                seq2 = decode.OpSequence(layers, xs, ys, batched=args.batch > 0, fuse_shared_input=args.group > 1)
                 plan = _lib.plan_query(args.bits, K, N, args.batch, nnz=layers[0]["vals"].numel() if args.sparse else 0, topX=args.topx)
                 seq2.profile(reps=1)
                 us = seq2.profile(reps=args.reps)
@@ -69,8 +70,8 @@ def main():
                 for _ in range(args.reps * 4):
                     g.replay()
                 torch.cuda.synchronize()
-                wall_us = (time.perf_counter() - t0) / (args.reps * 4) / len(layers) * 1e6
-                r = dict(shape=shp, bits=args.bits, batch=args.batch, variant=var, ablate=abl, target_wgs=tw, gpw=plan["groups_per_wave"], grid=plan["grid_x"],
+                wall_us = (time.perf_counter() - t0) / (args.reps * 4) / seq2.n_groups * 1e6
+                r = dict(shape=shp, group=args.group, bits=args.bits, batch=args.batch, variant=var, ablate=abl, target_wgs=tw, gpw=plan["groups_per_wave"], grid=plan["grid_x"],
                          k_slices=plan["k_slices"], wall_us=round(wall_us, 3), wall_GBps=round(nbytes / wall_us / 1e3, 1), us_mean=round(float(us.mean()), 3), us_min=round(float(us.min()), 3),
                          GBps=round(nbytes / us.mean() / 1e3, 1), frac=round(nbytes / us.mean() / 1e3 / 8000, 4), copies=copies)
                 rows.append(r)
