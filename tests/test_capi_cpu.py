@@ -160,3 +160,35 @@ def test_quantlinear_module_schema_matches_reference():
     assert QuantLinearLUT(4, 64, 64, False, include_sparse=True, numvals=3, balanced=True).op_kind(True) == "spmv"
     with pytest.raises(NotImplementedError):
         QuantLinearLUT(2, 64, 64, False)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/squeezellm/quant.py"), reason="reference tree only exists in the dev container")
+def test_unmodified_reference_quant_py_runs_on_this_quant_cuda():
+    """`import quant_cuda` at squeezellm/quant.py:5 must resolve to this repo's module, and the
+    reference's own QuantLinearLUT.forward must reach our operators with its own argument order
+    (checked with a recording double; the real call needs a GPU and is covered by -m gpu)."""
+    code = r'''
+import sys, contextlib, io
+sys.path.insert(0, %r); sys.path.insert(1, "/root/reference")
+import torch, quant_cuda
+import squeezellm_amd.quant_cuda as impl
+assert quant_cuda.vecquant4matmul_nuq_perchannel is impl.vecquant4matmul_nuq_perchannel
+from squeezellm import quant as refquant          # the UNMODIFIED reference module
+assert refquant.quant_cuda is quant_cuda
+calls = []
+for name in impl.__all__:
+    setattr(quant_cuda, name, (lambda n: (lambda *a: calls.append((n, len(a)))))(name))
+torch.zeros_orig = torch.zeros
+torch.zeros = lambda *a, **k: torch.zeros_orig(*a, **{**k, "device": "cpu"})   # quant.py:218 hard-codes "cuda"
+with contextlib.redirect_stdout(io.StringIO()):
+    dense = refquant.QuantLinearLUT(4, 128, 64, False)
+    hyb = refquant.QuantLinearLUT(3, 128, 64, False, include_sparse=True, numvals=5, topX=10)
+    bal = refquant.QuantLinearLUT(4, 128, 64, False, include_sparse=True, numvals=5, balanced=True)
+dense(torch.zeros(1, 1, 128)); dense(torch.zeros(3, 128)); hyb(torch.zeros(1, 128)); hyb(torch.zeros(2, 128)); bal(torch.zeros(128))
+assert calls == [("vecquant4matmul_nuq_perchannel", 4), ("vecquant4matmul_nuq_perchannel_batched", 4),
+                 ("vecquant3matmul_spmv_hybrid_nuq_perchannel", 10), ("vecquant3matmul_spmv_hybrid_nuq_perchannel_batched", 10),
+                 ("vecquant4matmul_spmv_balanced_nuq_perchannel", 11)], calls
+print("OK")
+''' % H.ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stderr[-2000:]
