@@ -14,13 +14,14 @@ constexpr int kTopxLds = 1024;     // topX up to which slab sums are kept in LDS
 constexpr int kMaxBatchTile = 8;   // batch rows handled per weight pass
 
 // LDS floats of one kernel instantiation: max over roles of
-//   dense: codebooks 4 sub-tables * lut_entries * (64 slots for 4-bit, 32 for 3-bit) ; cross-wave
-//          reduction waves * CB * 64
+//   dense: codebooks 4 column sub-tables * lut_entries * 32 slots (2 copies of 16 lanes) PLUS the
+//          cross-wave slabs waves * BT * 64 and the epilogue ticket (the slabs must not overlap
+//          the codebooks: the combine is barrier-free)
 //   csr  : kCsrSpanMax ints + kCsrSpanMax floats
 //   topx : kTopxLds
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
-constexpr int lds_floats(int lut_entries, int waves, int cb) {
-  return cmax(cmax(4 * lut_entries * (lut_entries == 16 ? 64 : 32), waves * cb * kTileN), cmax(2 * kCsrSpanMax, kTopxLds));
+constexpr int lds_floats(int lut_entries, int waves, int bt) {
+  return cmax(4 * lut_entries * 32 + waves * bt * kTileN + 4, cmax(2 * kCsrSpanMax, kTopxLds));
 }
 
 // Launch geometry, computed on the host (sqllm_capi.hip: make_plan) and passed by value.

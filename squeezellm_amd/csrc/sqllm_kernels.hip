@@ -188,15 +188,19 @@ __device__ __forceinline__ void step4(const u32x4& slot, const float (&xslot)[BT
   for (int j = 0; j < 4; ++j) {
     const uint32_t lo = t[j] & 0x0F0F0F0Fu;
     const uint32_t hi = (t[j] >> 4) & 0x0F0F0F0Fu;
+    // columns j and j^1 share 256-byte entry rows (even column in the low 128 bytes, odd in the
+    // high), the pair (j >> 1) selects the 4 KiB half: both fold into the ds_read immediate.
     // selector bytes (LSB first): byte0 <- lane_off.byte0, byte1 <- nibble word byte k, bytes 2,3 <- 0
-    v[j][0] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0400u) + j * 4096);
-    v[j][1] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0400u) + j * 4096);
-    v[j][2] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0500u) + j * 4096);
-    v[j][3] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0500u) + j * 4096);
-    v[j][4] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0600u) + j * 4096);
-    v[j][5] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0600u) + j * 4096);
-    v[j][6] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0700u) + j * 4096);
-    v[j][7] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0700u) + j * 4096);
+    constexpr int kNoOff = 0;
+    const int off = (j >> 1) * 4096 + (j & 1) * 128 + kNoOff;
+    v[j][0] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0400u) + off);
+    v[j][1] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0400u) + off);
+    v[j][2] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0500u) + off);
+    v[j][3] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0500u) + off);
+    v[j][4] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0600u) + off);
+    v[j][5] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0600u) + off);
+    v[j][6] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0700u) + off);
+    v[j][7] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0700u) + off);
   }
   fma_stage<BT, XL, ABL>(v, xv, acc);
   __builtin_amdgcn_sched_barrier(0);
@@ -249,8 +253,9 @@ __device__ __forceinline__ void step3(const u32x4 (&slot)[3], const float (&xslo
 //
 // Codebook layout in LDS (bytes):  addr(j, idx, slot) = j * SUBB + idx * ESTRIDE + 4 * slot
 //   j       = which dword of the lane's 16-byte load (the lane's j-th column)
-//   4-bit:  ESTRIDE = 256, slot = lane (four copies of the tile's 16 column groups, one per 16-lane
-//           row), SUBB = 4096 -- the layout the v_perm address generation wants
+//   4-bit:  256-byte entry rows (the stride the v_perm address generation wants), each holding the
+//           entry of an even column in its low 128 bytes and of the next odd column in its high
+//           128 bytes; slot as for 3-bit; two column pairs -> 2 x 4 KiB
 //   3-bit:  ESTRIDE = 128, slot = (lane & 15) + 16 * ((lane >> 4) & 1) (two copies: ds_read_b32 is
 //           serviced per half-wave of two rows), SUBB = 1024; idx * 128 is OR-ed into the base
 //   either way a lookup's bank depends on the lane only: lookups never conflict.
@@ -270,9 +275,8 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
   using F = Fmt<BITS>;
   constexpr int L = F::kLut;
   constexpr int R = F::kRows;
-  constexpr int COPIES = (BITS == 4) ? 4 : 2;
-  constexpr int ESTRIDE = COPIES * 64;           // bytes between consecutive entries
-  constexpr int SUBB = L * ESTRIDE;              // bytes per sub-table
+  constexpr int ESTRIDE = (BITS == 4) ? 256 : 128;                 // bytes between consecutive entries
+  constexpr int SUBB = (BITS == 4) ? (L * ESTRIDE) / 2 : L * ESTRIDE;  // LDS bytes per column sub-table
   // steps per chunk (4-bit: even, steps pair up for x; 3-bit: 12 VGPRs of weights per step)
   constexpr int NBUF = (BITS == 4) ? (BT <= 4 ? 4 : 2) : (BT == 1 ? 2 : 1);
   constexpr int NXR = (BITS == 4) ? NBUF / 2 : 2 * NBUF;  // x registers per chunk and batch row
@@ -341,25 +345,25 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
   // position in the row, so the writes of a half-wave hit 32 different banks.  (Letting thread t
   // write "its" float4 of the codebook block put 32 consecutive threads on 2 banks: 16-way
   // conflicts, measured as SQ_LDS_BANK_CONFLICT ~ SQ_ACTIVE_INST_LDS and 1-2 us per launch.)
-  //   4-bit: row = (column j, entry idx), 64 slots = 4 copies x 16 column groups;
-  //          wave w stages column j = w % 4, entries [(w / 4) * EPW, + EPW), EPW = 64 / WAVES.
+  //   4-bit: row = (column pair, entry idx): 32 slots of the even column, 32 of the odd one
+  //          (2 copies x 16 column groups each); wave w stages pair w % 2, entries
+  //          [(w / 2) * EPW, + EPW), EPW = 32 / WAVES; lane >> 5 picks even / odd.
   //   3-bit: row = (column j, entry pair), 2 entries x 32 slots (2 copies x 16 column groups);
   //          wave w stages column j = w % 4, pairs [(w / 4) * RPW, + RPW), RPW = 16 / WAVES.
-  constexpr int EPW = 64 / WAVES;                       // 4-bit: entries per wave
+  constexpr int EPW = 32 / WAVES;                       // 4-bit: entries per wave
   constexpr int RPW = 16 / WAVES;                       // 3-bit: entry pairs per wave
   constexpr int NE = (BITS == 4) ? EPW : RPW;           // codebook values this thread stages
   float ev[NE];
-  const int st_j = wave & 3, st_h = wave >> 2;
+  const int st_j = (BITS == 4) ? 2 * (wave & 1) + (lane >> 5) : (wave & 3);  // column this lane stages
+  const int st_h = (BITS == 4) ? (wave >> 1) : (wave >> 2);
   if constexpr (!(ABL & 4)) {
-    int c = col0 + 4 * i16 + st_j;  // the column whose entries this lane stages
+    int c = col0 + 4 * i16 + st_j;
     if (c > N - 1) c = N - 1;
     const float* src = lut + (size_t)c * L;
     if constexpr (BITS == 4) {
-#pragma unroll
-      for (int v4 = 0; v4 < EPW / 4; ++v4) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(src + st_h * EPW + 4 * v4);
-        ev[4 * v4 + 0] = t.x; ev[4 * v4 + 1] = t.y; ev[4 * v4 + 2] = t.z; ev[4 * v4 + 3] = t.w;
-      }
+      static_assert(EPW == 4, "4-bit staging assumes 8 waves: one float4 per thread");
+      const f32x4 t = *reinterpret_cast<const f32x4*>(src + st_h * EPW);
+      ev[0] = t.x; ev[1] = t.y; ev[2] = t.z; ev[3] = t.w;
     } else {
 #pragma unroll
       for (int i = 0; i < RPW; ++i) ev[i] = src[2 * (st_h * RPW + i) + (lane >> 5)];
@@ -372,10 +376,13 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 
+  constexpr int kCodebookFloats = 4 * SUBB / 4;  // the four column sub-tables
+  if (tid == 0) *reinterpret_cast<unsigned*>(lds + kCodebookFloats + WAVES * BT * kTileN) = 0u;  // epilogue ticket
   // ---- stage the codebooks (row-wise, see above) ----
   if constexpr (!(ABL & 4)) {
     if constexpr (BITS == 4) {
-      float* dst = lds + (st_j * SUBB + st_h * EPW * ESTRIDE) / 4 + lane;
+      // row (pair, idx) starts at pair * 4096 + idx * 256; this lane's dword in it is `lane`
+      float* dst = lds + ((wave & 1) * 4096 + st_h * EPW * ESTRIDE) / 4 + lane;
 #pragma unroll
       for (int i = 0; i < EPW; ++i) dst[i * (ESTRIDE / 4)] = ev[i];
     } else {
@@ -393,7 +400,7 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
     for (int b = 0; b < BT; ++b) acc[j][b] = 0.f;
 
   // per-lane LDS byte offset inside an entry row (4-bit) / per-sub-table bases (3-bit)
-  const uint32_t lane_off = 4 * lane;
+  const uint32_t lane_off = 4 * (i16 + 16 * (grp & 1));  // 4-bit: dword slot inside a 128-byte half row
   uint32_t tb[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) tb[j] = j * SUBB + 4 * (i16 + 16 * (grp & 1));
@@ -441,27 +448,49 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
       a += __shfl_xor(a, 32, 64);
       acc[j][b] = a;
     }
-  constexpr int CB = BT < 4 ? BT : 4;
-  float* red = lds;  // [wave][CB][64]
-#pragma unroll
-  for (int c0 = 0; c0 < BT; c0 += CB) {
-    __syncthreads();
+  if constexpr (ABL & 32) {
+    // variant: no cross-wave combine, every wave adds its own 64 partial sums
     if (grp == 0) {
 #pragma unroll
-      for (int b = 0; b < CB; ++b) {
-        f32x4 v = {acc[0][c0 + b], acc[1][c0 + b], acc[2][c0 + b], acc[3][c0 + b]};
-        *reinterpret_cast<f32x4*>(red + (wave * CB + b) * kTileN + 4 * i16) = v;
+      for (int j = 0; j < 4; ++j) {
+        const int c = col0 + 4 * i16 + j;
+#pragma unroll
+        for (int b = 0; b < BT; ++b)
+          if (c < N && b < nb) atomicAdd(y + (size_t)(b0 + b) * N + c, acc[j][b]);
       }
     }
-    __syncthreads();
-    if (tid < CB * kTileN) {
-      const int b = tid / kTileN, cc = tid % kTileN;
-      const int c = col0 + cc;
-      if (c < N && c0 + b < nb) {
+    return;
+  }
+  // Barrier-free combine: every wave deposits its 64 x BT partial sums in its own LDS slab (a
+  // region the codebooks never occupy, so nobody has to wait for the other waves' lookups), then
+  // takes a ticket; the wave that draws the last ticket sums the slabs and issues the atomics.
+  // Waves that finish early simply leave.  (LDS operations of a CU execute in issue order and a
+  // wave's own LDS operations stay in program order, so the last ticket implies every slab is
+  // written; the fence pins the compiler.)  The two-barrier version cost 1-2.5 us per launch.
+  float* red = lds + kCodebookFloats;                                      // [wave][BT][64]
+  unsigned* ticket = reinterpret_cast<unsigned*>(lds + kCodebookFloats + WAVES * BT * kTileN);
+  if (grp == 0) {
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      f32x4 v = {acc[0][b], acc[1][b], acc[2][b], acc[3][b]};
+      *reinterpret_cast<f32x4*>(red + (wave * BT + b) * kTileN + 4 * i16) = v;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  unsigned t = 0;
+  if (lane == 0) t = atomicAdd(ticket, 1u);
+  t = __builtin_amdgcn_readfirstlane(t);
+  if (t != WAVES - 1) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const int c = col0 + lane;
+  if (c < N) {
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      if (b < nb) {
         float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) sum += red[(w * CB + b) * kTileN + cc];
-        atomicAdd(y + (size_t)(b0 + c0 + b) * N + c, sum);
+        for (int w = 0; w < WAVES; ++w) sum += red[(w * BT + b) * kTileN + lane];
+        atomicAdd(y + (size_t)(b0 + b) * N + c, sum);
       }
     }
   }
@@ -626,11 +655,10 @@ __device__ __forceinline__ void topx_role(const float* x, float* __restrict__ y,
 template <int BITS, int BT, int WAVES, int ABL = 0>
 // occupancy target: 2 workgroups of 8 waves per CU (<= 128 VGPRs); the 3-bit kernels with a wide
 // batch tile need more registers and settle for one workgroup per CU rather than spill
-__global__ void __launch_bounds__(WAVES * 64, (BITS == 3 && BT >= 4) ? 2 : 4)
+__global__ void __launch_bounds__(WAVES * 64, (ABL & 64) ? 8 : (BITS == 3 && BT >= 4) ? 2 : 4)
 sqllm_fused_matvec(const float* x, const GroupArgs ga) {
   constexpr int T = WAVES * 64;
-  constexpr int CB = BT < 4 ? BT : 4;
-  constexpr int kLds = lds_floats(Fmt<BITS>::kLut, WAVES, CB);
+  constexpr int kLds = lds_floats(Fmt<BITS>::kLut, WAVES, BT);
   __shared__ __attribute__((aligned(16))) float lds[kLds];
 
   // which op of the launch this workgroup belongs to (wave-uniform; 1 segment = a plain op)
@@ -784,6 +812,8 @@ hipError_t launch_fused(int bits, const LaunchArgs& a, hipStream_t stream) {
       case 13: return launch_inst<4, 1, kWaves, 13>(a, stream);
       case 14: return launch_inst<4, 1, kWaves, 14>(a, stream);
       case 16: return launch_inst<4, 1, kWaves, 16>(a, stream);
+      case 32: return launch_inst<4, 1, kWaves, 32>(a, stream);
+      case 40: return launch_inst<4, 1, kWaves, 128>(a, stream);  // option value 40 = ABL bit 128
       default: break;
     }
   }
