@@ -132,8 +132,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SQLLM_BENCH_FORCE_DIST=1 initialises RCCL even for one rank (smoke test of the N > 1 plumbing)
+    use_dist = world > 1 or os.environ.get("SQLLM_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     spec = synth.MODEL_SHAPES[cfg["model"]]
@@ -143,8 +146,8 @@ def main():
     mode = args.parallel
     if mode == "auto":
         mode = "pipeline" if (world > 1 and args.config.startswith("65b")) else "replicas"
-    if world == 1:
-        mode = "replicas"
+    if world == 1 and args.parallel != "pipeline":
+        mode = "replicas"  # (an explicit --parallel pipeline on one GPU runs a ring of one stage)
     lo, hi = sharding.partition_layers(model_layers, world)[rank] if mode == "pipeline" else (0, model_layers)
 
     # ---- build this rank's layers (distinct weights per linear), resident in HBM ----
@@ -189,7 +192,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -201,7 +204,7 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -242,7 +245,7 @@ def main():
         },
     }
 
-    if world == 1 and rank == 0:
+    if world == 1 and rank == 0 and mode == "replicas":
         pass_bytes = float(sum(bytes_per_op))
         result["hbm_frac_wall"] = round(pass_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if not args.no_roofline:
@@ -286,7 +289,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
