@@ -37,6 +37,8 @@ int validate(const sqllm_op* op) {
   if (!op) return SQLLM_E_NULL;
   if (op->bits != 3 && op->bits != 4) return SQLLM_E_BITS;
   if (op->K <= 0 || op->N <= 0 || (op->K % 32) != 0 || (op->N % 4) != 0) return SQLLM_E_SHAPE;
+  // the kernels address qweight with 32-bit byte offsets
+  if ((uint64_t)op->K / 32u * (uint64_t)op->bits * (uint64_t)op->N * 4u >= (1ull << 32)) return SQLLM_E_SHAPE;
   if (op->batch < 0) return SQLLM_E_BATCH;
   if (!op->vec || !op->qweight || !op->mul || !op->lookup_table) return SQLLM_E_NULL;
   if ((reinterpret_cast<uintptr_t>(op->qweight) & 15u) != 0 ||

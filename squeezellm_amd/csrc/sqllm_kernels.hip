@@ -289,33 +289,43 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
   const int ks = bid / n_col_tiles;
   const int col0 = ct * kTileN;
 
-  // ---- this workgroup's K range in units; u - grp is wave-uniform for every unit index u below
+  // ---- this workgroup's K range in units.  u_wave (this wave's first unit) is wave-uniform and
+  //      drives every loop / guard; a lane's own unit is u_wave + grp (+ step offsets).
   const int u_beg = ks * units_per_wg;
   int u_end = u_beg + units_per_wg;
   if (u_end > units_total) u_end = units_total;
   const int u_last = u_end - 1;
-  const int u_first = u_beg + wave * 4 + grp;  // + s * STEP
+  const int u_wave = u_beg + wave * 4;
 
   // Loads are UNCONDITIONAL with clamped addresses (a conditional load becomes a branch with an
   // immediate vmcnt(0)): lanes past N re-read the last valid 16 bytes of the row; steps past the
   // end of THIS workgroup's slice re-read the slice's own last unit (a cache hit -- clamping only
   // to the end of the matrix pulls other slices' rows from HBM: at 2-6 steps per wave that
   // over-fetch was 30-100 % of the useful traffic).  Such data is never accumulated.
+  // Addresses are a wave-uniform base plus a 32-bit byte offset (one v_mul_u32_u24 + add per load;
+  // 64-bit index arithmetic cost a v_mad_i64 and a 64-bit shift-add per load in an issue-bound
+  // kernel).  The C ABI rejects matrices of 4 GiB or more.
   const int row_stride = N / 4;  // in 16-byte units
   int cidx = col0 / 4 + i16;
   if (cidx > row_stride - 1) cidx = row_stride - 1;
-  const u32x4* qcol = q + cidx;
-  const float* xrow[BT];
+  const char* qbase = reinterpret_cast<const char*>(q);
+  const uint32_t lane_bytes = 16u * (uint32_t)cidx;
+  const uint32_t row_bytes = 16u * (uint32_t)row_stride;
+  const uint32_t unit_bytes = (uint32_t)R * row_bytes;
+  const char* xbase[BT];
 #pragma unroll
-  for (int b = 0; b < BT; ++b) xrow[b] = x + (size_t)(b0 + (b < nb ? b : nb - 1)) * K;
+  for (int b = 0; b < BT; ++b) xbase[b] = reinterpret_cast<const char*>(x + (size_t)(b0 + (b < nb ? b : nb - 1)) * K);
 
+  // u = this wave's (uniform) unit for the chunk's first step; the lane's unit is u + grp
   auto load_chunk = [&](int u, u32x4 (&w)[NBUF][R], float (&xs)[NXR][BT]) {
 #pragma unroll
     for (int s = 0; s < NBUF; ++s) {
-      int uu = u + s * STEP;
+      int uu = u + grp + s * STEP;
       if (uu > u_last) uu = u_last;
+      const uint32_t off = __umul24((uint32_t)uu, unit_bytes) + lane_bytes;
 #pragma unroll
-      for (int r = 0; r < R; ++r) w[s][r] = __builtin_nontemporal_load(qcol + (size_t)(uu * R + r) * row_stride);
+      for (int r = 0; r < R; ++r)
+        w[s][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(qbase + (off + r * row_bytes)));
     }
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
@@ -324,17 +334,19 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
         // lanes 8-15 the second step's
 #pragma unroll
         for (int s2 = 0; s2 < NBUF / 2; ++s2) {
-          int uu = u + (2 * s2 + (i16 >> 3)) * STEP;
+          int uu = u + grp + (2 * s2 + (i16 >> 3)) * STEP;
           if (uu > u_last) uu = u_last;
-          xs[s2][b] = (ABL & 16) ? 1.f + i16 : xrow[b][uu * 8 + (i16 & 7)];
+          const uint32_t off = 32u * (uint32_t)uu + 4u * (i16 & 7);
+          xs[s2][b] = (ABL & 16) ? 1.f + i16 : *reinterpret_cast<const float*>(xbase[b] + off);
         }
       } else {
 #pragma unroll
         for (int s = 0; s < NBUF; ++s) {
-          int uu = u + s * STEP;
+          int uu = u + grp + s * STEP;
           if (uu > u_last) uu = u_last;
-          xs[2 * s][b] = xrow[b][uu * 32 + i16];
-          xs[2 * s + 1][b] = xrow[b][uu * 32 + 16 + i16];
+          const uint32_t off = 128u * (uint32_t)uu + 4u * i16;
+          xs[2 * s][b] = *reinterpret_cast<const float*>(xbase[b] + off);
+          xs[2 * s + 1][b] = *reinterpret_cast<const float*>(xbase[b] + off + 64);
         }
       }
     }
@@ -371,7 +383,7 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
   }
   u32x4 w0[NBUF][R];
   float x0[NXR][BT];
-  load_chunk(u_first, w0, x0);
+  load_chunk(u_wave, w0, x0);
   // keep these loads ABOVE the staging barrier (LLVM would otherwise sink them below it)
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -407,25 +419,27 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
 
   __syncthreads();  // codebooks visible
 
+  // u = this wave's (uniform) unit for the chunk's first step: guards are scalar branches; only the
+  // per-row validity of a slice's ragged end is per lane (it zeroes x, no divergence)
   auto decode_chunk = [&](int u, const u32x4 (&w)[NBUF][R], const float (&xs)[NXR][BT]) {
     if constexpr (BITS == 4) {
 #pragma unroll
       for (int s2 = 0; s2 < NBUF / 2; ++s2) {
         const int ua = u + 2 * s2 * STEP, ub = ua + STEP;
-        if (ua - grp < u_end) step4<BT, 0, ABL>(w[2 * s2][0], xs[s2], ua < u_end, lane_off, acc);      // wave-uniform
-        if (ub - grp < u_end) step4<BT, 8, ABL>(w[2 * s2 + 1][0], xs[s2], ub < u_end, lane_off, acc);  // wave-uniform
+        if (ua < u_end) step4<BT, 0, ABL>(w[2 * s2][0], xs[s2], ua + grp < u_end, lane_off, acc);
+        if (ub < u_end) step4<BT, 8, ABL>(w[2 * s2 + 1][0], xs[s2], ub + grp < u_end, lane_off, acc);
       }
     } else {
 #pragma unroll
       for (int s = 0; s < NBUF; ++s) {
         const int ua = u + s * STEP;
-        if (ua - grp < u_end) step3<BT, ABL>(w[s], xs[2 * s], xs[2 * s + 1], ua < u_end, tb, acc);  // wave-uniform
+        if (ua < u_end) step3<BT, ABL>(w[s], xs[2 * s], xs[2 * s + 1], ua + grp < u_end, tb, acc);
       }
     }
   };
 
-  decode_chunk(u_first, w0, x0);
-  for (int u0 = u_first + NBUF * STEP; u0 - grp < u_end; u0 += NBUF * STEP) {  // wave-uniform trip count
+  decode_chunk(u_wave, w0, x0);
+  for (int u0 = u_wave + NBUF * STEP; u0 < u_end; u0 += NBUF * STEP) {  // scalar loop
     u32x4 w[NBUF][R];
     float xs[NXR][BT];
     load_chunk(u0, w, xs);
