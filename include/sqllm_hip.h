@@ -104,6 +104,42 @@ int sqllm_profile_groups(const sqllm_op* ops, const int32_t* group_sizes, int32_
                          sqllm_stream_t stream, int32_t reps, float* avg_us);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused linear: the whole matvec branch of QuantLinearLUT.forward in one kernel.
+ *
+ * The reference wraps every operator call in three more launches -- `y = bias.clone()` or
+ * `torch.zeros`, `x.float()`, `y.to(fp16)` (squeezellm/quant.py:214-223, :311-312; batched:
+ * :314-321, :380-383).  sqllm_linear_f16 takes the activations as fp16 and writes fp16:
+ *
+ *     out[b, n] = fp16( bias[n] + sum_k W[n, k] * float(x[b, k]) )      (all three weight terms)
+ *
+ * `op` is read as for sqllm_launch except that  op.vec  is  const _Float16* [batch, K]  and
+ * op.mul  is  _Float16* [batch, N], OVERWRITTEN (not accumulated into).  Accumulation is fp32.
+ * `workspace`: sqllm_linear_workspace_bytes(&op) bytes of device memory, 16-byte aligned, that the
+ * caller zero-fills ONCE; every launch leaves it zero-filled again.  A workspace serves one
+ * launch at a time (launches on one stream may share it; concurrent streams may not).
+ * Like every entry point: one kernel, nothing allocated, nothing retained, no synchronisation.
+ * Accumulation runs in 2^-28 fixed point inside the workspace (so that one returning atomic both
+ * deposits a partial sum and counts it): every partial sum is clamped to +-131072 (2 x the
+ * largest finite fp16; a NaN partial sum counts as -131072), i.e. results are exact to well below
+ * one fp16 ulp wherever the fp16 result is finite.  The CSR operands must be consistent
+ * (rows[N] == nnz, rows non-decreasing): completion is detected by counting the contributions
+ * `rows` announces.  Shapes whose columns could receive more than 511 partial sums (K beyond
+ * ~400 k) are rejected with SQLLM_E_SHAPE.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct sqllm_linear {
+  sqllm_op op;
+  const float* bias; /* fp32 [N] or NULL */
+  void* workspace;
+} sqllm_linear;
+
+int64_t sqllm_linear_workspace_bytes(const sqllm_op* op);
+int sqllm_linear_f16(const sqllm_linear* lin, sqllm_stream_t stream);
+/* a pass of fused linears as consecutive same-input groups (cf. sqllm_launch_groups); the members
+ * of a group share op.vec, K, bits and batch and each has its own workspace */
+int sqllm_linear_f16_groups(const sqllm_linear* lins, const int32_t* group_sizes, int32_t n_groups,
+                            sqllm_stream_t stream, int32_t* n_done);
+
+/* ---------------------------------------------------------------------------------------------
  * The reference operator names.
  * height/width = mat.size(0)/mat.size(1) of the qweight tensor (quant_cuda_kernel.cu:138-139).
  * ------------------------------------------------------------------------------------------- */

@@ -35,6 +35,12 @@ class SqllmOp(ctypes.Structure):
     ]
 
 
+class SqllmLinear(ctypes.Structure):
+    """struct sqllm_linear (include/sqllm_hip.h): op.vec / op.mul carry fp16 pointers."""
+
+    _fields_ = [("op", SqllmOp), ("bias", c_void_p), ("workspace", c_void_p)]
+
+
 class SqllmPlan(ctypes.Structure):
     """struct sqllm_plan (include/sqllm_hip.h)."""
 
@@ -60,6 +66,9 @@ SIGNATURES = {
     "sqllm_launch_group": [POINTER(SqllmOp), c_int32, P],
     "sqllm_launch_groups": [POINTER(SqllmOp), POINTER(c_int32), c_int32, P, POINTER(c_int32)],
     "sqllm_profile_groups": [POINTER(SqllmOp), POINTER(c_int32), c_int32, P, c_int32, POINTER(ctypes.c_float)],
+    "sqllm_linear_workspace_bytes": [POINTER(SqllmOp)],
+    "sqllm_linear_f16": [POINTER(SqllmLinear), P],
+    "sqllm_linear_f16_groups": [POINTER(SqllmLinear), POINTER(c_int32), c_int32, P, POINTER(c_int32)],
     "sqllm_abi_version": [],
     "sqllm_error_string": [c_int],
     "sqllm_set_option": [c_char_p, c_int],
@@ -92,7 +101,8 @@ def load() -> ctypes.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = argtypes
-        fn.restype = c_char_p if name == "sqllm_error_string" else c_int
+        fn.restype = (c_char_p if name == "sqllm_error_string" else
+                      ctypes.c_int64 if name == "sqllm_linear_workspace_bytes" else c_int)
     if lib.sqllm_abi_version() != 1:
         raise RuntimeError(f"libsqllm_hip.so ABI {lib.sqllm_abi_version()} != 1 expected by this package")
     _lib = lib
@@ -117,6 +127,12 @@ def get_option(name: str) -> int:
     v = c_int(0)
     check(load().sqllm_get_option(name.encode(), ctypes.byref(v)), f"sqllm_get_option({name})")
     return v.value
+
+
+def linear_workspace_bytes(N: int, batch: int = 0) -> int:
+    """Bytes of zero-filled device memory one fused linear of this shape needs (no GPU needed)."""
+    op = SqllmOp(N=N, batch=batch)
+    return int(load().sqllm_linear_workspace_bytes(ctypes.byref(op)))
 
 
 def plan_query(bits: int, K: int, N: int, batch: int = 0, nnz: int = 0, topX: int = 0) -> dict:

@@ -79,6 +79,7 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm) {
     }
     int slices = (target + gm->col_tiles / 2) / gm->col_tiles;
     if (slices < 1) slices = 1;
+    if (slices > sqllm::kMaxSlices) slices = sqllm::kMaxSlices;
     upw = (gm->units_total + slices - 1) / slices;
   }
   upw = (upw + step - 1) / step * step;
@@ -157,12 +158,31 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   return SQLLM_OK;
 }
 
-// One kernel over 1..kMaxSegments ops that share vec, K, bits and batch.
+static int64_t align16(int64_t v) { return (v + 15) / 16 * 16; }
+
+// workspace of a fused linear: 64-bit accumulator words [batch, N]
+int64_t sqllm_linear_workspace_bytes(const sqllm_op* op) {
+  if (!op || op->N <= 0) return 0;
+  return align16(8ll * (op->batch <= 0 ? 1 : op->batch) * op->N);
+}
+
+// One kernel over 1..kMaxSegments ops that share vec, K, bits and batch.  `lin` (optional) points at
+// the fused-linear descriptors the ops were taken from: `ops` is then lin[i].op.
 static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t stream, hipEvent_t e0,
-                                    hipEvent_t e1) {
+                                    hipEvent_t e1, const sqllm_linear* lin = nullptr) {
   if (n < 1 || n > sqllm::kMaxSegments) return SQLLM_E_GROUP;
-  if (!ops) return SQLLM_E_NULL;
+  if (!ops && !lin) return SQLLM_E_NULL;
+  sqllm_op tmp[sqllm::kMaxSegments];
+  if (lin) {
+    for (int i = 0; i < n; ++i) {
+      tmp[i] = lin[i].op;
+      if (!lin[i].workspace) return SQLLM_E_NULL;
+      if ((reinterpret_cast<uintptr_t>(lin[i].workspace) & 15u) != 0) return SQLLM_E_ALIGN;
+    }
+    ops = tmp;
+  }
   sqllm::LaunchArgs a;
+  a.linear = lin != nullptr;
   a.ev_start = e0;
   a.ev_stop = e1;
   a.ablate = g_ablate.load(std::memory_order_relaxed);
@@ -185,7 +205,23 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     sg.vals = op->vals;
     sg.full_rows = op->full_rows;
     sg.full_idx = op->full_row_indices;
+    sg.bias = nullptr;
+    sg.out16 = nullptr;
     make_plan(op, &sg.gm);
+    if (lin) {
+      // accumulate into the workspace plane; op->mul is the fp16 result
+      sg.y = reinterpret_cast<float*>(lin[i].workspace);
+      sg.out16 = op->mul;
+      sg.bias = lin[i].bias;
+      // the top-X rows are handled inside the dense workgroups: no top-X role in the grid
+      sg.gm.topx_blocks = 0;
+      if (!sg.gm.sparse_last) sg.gm.dense_block0 = (sg.gm.csr_blocks + 7) / 8 * 8;
+      else sg.gm.dense_block0 = sg.gm.csr_blocks;
+      // the 55-bit sum field holds at most kMaxContrib clamped contributions per column: the K
+      // slices and one per CSR chunk a row can be spread over
+      if (sg.gm.k_slices + (sg.gm.csr_blocks ? op->K / sqllm::kCsrChunk + 2 : 0) > sqllm::kMaxContrib)
+        return SQLLM_E_SHAPE;
+    }
     a.ga.block0[i] = block;
     // pad every segment to a multiple of 8 workgroups: dense ids keep their XCD alignment
     block += (sg.gm.dense_block0 + sg.gm.dense_blocks + 7) / 8 * 8;
@@ -193,6 +229,26 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
   for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
   for (int i = n; i < sqllm::kMaxSegments; ++i) memset(&a.ga.seg[i], 0, sizeof(sqllm::Segment));
   return static_cast<int>(sqllm::launch_fused(ops[0].bits, a, static_cast<hipStream_t>(stream)));
+}
+
+int sqllm_linear_f16(const sqllm_linear* lin, sqllm_stream_t stream) {
+  if (!lin) return SQLLM_E_NULL;
+  return launch_group_with_events(nullptr, 1, stream, nullptr, nullptr, lin);
+}
+
+int sqllm_linear_f16_groups(const sqllm_linear* lins, const int32_t* group_sizes, int32_t n_groups,
+                            sqllm_stream_t stream, int32_t* n_done) {
+  if (n_done) *n_done = 0;
+  if (n_groups < 0 || (n_groups > 0 && (!lins || !group_sizes))) return SQLLM_E_NULL;
+  int32_t at = 0;
+  for (int32_t g = 0; g < n_groups; ++g) {
+    if (group_sizes[g] < 1) return SQLLM_E_GROUP;
+    int rc = launch_group_with_events(nullptr, group_sizes[g], stream, nullptr, nullptr, lins + at);
+    if (rc != SQLLM_OK) return rc;
+    at += group_sizes[g];
+    if (n_done) *n_done = g + 1;
+  }
+  return SQLLM_OK;
 }
 
 int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream) {

@@ -12,16 +12,18 @@ constexpr int kCsrSpanMax = 2048;  // CSR rows a chunk may span and still accumu
 constexpr int kTopxRows = 128;     // k's per top-X slab
 constexpr int kTopxLds = 1024;     // topX up to which slab sums are kept in LDS
 constexpr int kMaxBatchTile = 8;   // batch rows handled per weight pass
+constexpr int kMaxSlices = 120;    // K slices per column tile
+constexpr int kMaxContrib = 511;   // fused linear: contributions one column may receive (9-bit count)
 
 // LDS floats of one kernel instantiation: max over roles of
 //   dense: codebooks 4 column sub-tables * lut_entries * 32 slots (2 copies of 16 lanes) PLUS the
-//          cross-wave slabs waves * BT * 64 and the epilogue ticket (the slabs must not overlap
-//          the codebooks: the combine is barrier-free)
+//          cross-wave slabs waves * BT * 64, the epilogue ticket and the fused linear's top-X
+//          sums BT * 64 (the slabs must not overlap the codebooks: the combine is barrier-free)
 //   csr  : kCsrSpanMax ints + kCsrSpanMax floats
 //   topx : kTopxLds
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int lds_floats(int lut_entries, int waves, int bt) {
-  return cmax(4 * lut_entries * 32 + waves * bt * kTileN + 4, cmax(2 * kCsrSpanMax, kTopxLds));
+  return cmax(4 * lut_entries * 32 + waves * bt * kTileN + 4 + bt * kTileN, cmax(2 * kCsrSpanMax, kTopxLds));
 }
 
 // Launch geometry, computed on the host (sqllm_capi.hip: make_plan) and passed by value.
@@ -51,6 +53,11 @@ struct Segment {
   const float* vals;
   const float* full_rows;
   const int* full_idx;
+  // fused-linear launches only (sqllm_linear_f16): `y` is then the plane of 64-bit accumulator
+  // words [batch, N] in the caller's workspace (all zero between launches) and the finished
+  // columns leave as fp16
+  const float* bias;    // fp32 [N] or null
+  void* out16;          // fp16 [batch, N]
   KernelGeom gm;
 };
 
@@ -64,7 +71,8 @@ struct GroupArgs {
 };
 
 struct LaunchArgs {
-  const float* x;
+  const void* x;        // fp32 (operator launches) or fp16 (fused-linear launches)
+  bool linear = false;  // fused-linear launch: fp16 in / fp16 out, bias, self-cleaning workspace
   GroupArgs ga;
   hipEvent_t ev_start = nullptr;  // optional: recorded at this kernel's begin / end (profiling aid)
   hipEvent_t ev_stop = nullptr;

@@ -61,6 +61,12 @@ template <> struct Fmt<3> {
   static constexpr int kRows = 3;
   static constexpr int kK = 32;
 };
+// element type of vec: fp32 behind the reference operator names, fp16 for the fused linear
+template <bool LIN> struct XType { using type = float; };
+template <> struct XType<true> { using type = _Float16; };
+// accumulator word: the caller's fp32 `mul`, or the fused linear's fixed-point workspace plane
+template <bool LIN> struct AccType { using type = float; };
+template <> struct AccType<true> { using type = unsigned long long; };
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -249,6 +255,61 @@ __device__ __forceinline__ void step3(const u32x4 (&slot)[3], const float (&xslo
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused-linear completion (sqllm_linear_f16: fp16 in, fp16 out, bias, no launches around the op --
+// the reference wraps every op in a zeros/clone, an x.float() and a y.to(fp16) kernel,
+// squeezellm/quant.py:214-223,311-312).
+//
+// The roles accumulate into a plane of 64-bit words in the caller's workspace, all zero between
+// launches.  A word is  count * 2^55 + S  with S the column's sum in signed fixed point (2^-28
+// units): integer adds commute, so ONE returning atomic add both deposits a contribution and
+// tells the contributor how many have arrived.  How many a column will receive is known to every
+// contributor without communication:
+//     every dense K slice of the column's tile            -> k_slices
+//   + every CSR chunk that holds part of the column's row -> from rows[c], rows[c+1] alone
+// (the top-X rows are folded into the dense workgroups of the tiles that own their columns, see
+// dense_role).  Whoever deposits the last contribution owns the column: bias, fp16 store, word
+// back to zero.  The critical path of a workgroup grows by one atomic round trip; there are no
+// fences (an agent-scope release/acquire pair costs an L2 write-back and an L2 invalidate per
+// workgroup here: measured +4.5 us per launch) and no launch-wide counter (a last-arriver that
+// must then touch all N columns measured +4-11 us per launch).
+//
+// Contributions are clamped to +-2^17 (twice the largest finite fp16) so that the at most 511 of
+// them a column can receive stay inside the 55-bit field; sums beyond that are not finite in
+// fp16 anyway.  Rounding: 2^-28 absolute per contribution, far below one fp16 ulp of any normal
+// fp16 result.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned long long u64;
+constexpr int kFixShift = 28;
+constexpr int kCountShift = 55;
+constexpr u64 kCountUnit = 1ull << kCountShift;
+
+__device__ __forceinline__ u64 to_fixed(float v) {
+  v = __builtin_fminf(__builtin_fmaxf(v, -131072.f), 131072.f);  // also maps NaN to a bound
+  return (u64)(long long)__builtin_rintf(v * (float)(1 << kFixShift));
+}
+
+// CSR chunks (kCsrChunk consecutive non-zeros each) holding part of a row that spans [r0, r1)
+__device__ __forceinline__ int csr_chunks_of_row(int r0, int r1) {
+  return r1 > r0 ? (r1 - 1) / kCsrChunk - r0 / kCsrChunk + 1 : 0;
+}
+
+// `total` = the word after this thread's own counted add.  Finishes the column if that add was the
+// last of the `target` contributions.
+__device__ __forceinline__ void column_done(const Segment& sg, u64* word, u64 total, unsigned target,
+                                            size_t at, int c) {
+  const u64 count = (total + (kCountUnit >> 1)) >> kCountShift;  // S may be negative: round, do not truncate
+  if ((unsigned)count != target) return;
+  const long long sfix = (long long)(total - (count << kCountShift));
+  const float v = (float)sfix * (1.f / (float)(1 << kFixShift)) + (sg.bias ? sg.bias[c] : 0.f);
+  reinterpret_cast<_Float16*>(sg.out16)[at] = (_Float16)v;
+  atomicExch(word, 0ull);  // result unused: a plain atomic store
+}
+
+// accumulate one UNCOUNTED value: fp32 atomic (operator launches) or fixed-point add (fused linear)
+__device__ __forceinline__ void acc_add(float* p, float v) { atomicAdd(p, v); }
+__device__ __forceinline__ void acc_add(u64* p, float v) { atomicAdd(p, to_fixed(v)); }
+
+// ------------------------------------------------------------------------------------------------
 // dense role
 //
 // Codebook layout in LDS (bytes):  addr(j, idx, slot) = j * SUBB + idx * ESTRIDE + 4 * slot
@@ -268,11 +329,13 @@ __device__ __forceinline__ void step3(const u32x4 (&slot)[3], const float (&xslo
 // address arithmetic cost more VALU than the overlap returns), and 16 waves per CU at different
 // phases keep the memory pipe busy.
 // ------------------------------------------------------------------------------------------------
-template <int BITS, int BT, int WAVES, int ABL = 0>
-__device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float* __restrict__ y,
+template <int BITS, int BT, int WAVES, int ABL, typename XT>
+__device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* __restrict__ y,
                                            const float* lut, int K, int N, int b0, int nb, int bid,
-                                           int n_col_tiles, int units_total, int units_per_wg, float* lds) {
+                                           int n_col_tiles, int units_total, int units_per_wg, float* lds,
+                                           const Segment* lin) {
   using F = Fmt<BITS>;
+  constexpr uint32_t XB = sizeof(XT);  // bytes per element of vec (4: operator ABI, 2: fused linear)
   constexpr int L = F::kLut;
   constexpr int R = F::kRows;
   constexpr int ESTRIDE = (BITS == 4) ? 256 : 128;                 // bytes between consecutive entries
@@ -336,17 +399,17 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
         for (int s2 = 0; s2 < NBUF / 2; ++s2) {
           int uu = u + grp + (2 * s2 + (i16 >> 3)) * STEP;
           if (uu > u_last) uu = u_last;
-          const uint32_t off = 32u * (uint32_t)uu + 4u * (i16 & 7);
-          xs[s2][b] = (ABL & 16) ? 1.f + i16 : *reinterpret_cast<const float*>(xbase[b] + off);
+          const uint32_t off = XB * (8u * (uint32_t)uu + (i16 & 7));
+          xs[s2][b] = (ABL & 16) ? 1.f + i16 : (float)*reinterpret_cast<const XT*>(xbase[b] + off);
         }
       } else {
 #pragma unroll
         for (int s = 0; s < NBUF; ++s) {
           int uu = u + grp + s * STEP;
           if (uu > u_last) uu = u_last;
-          const uint32_t off = 128u * (uint32_t)uu + 4u * i16;
-          xs[2 * s][b] = *reinterpret_cast<const float*>(xbase[b] + off);
-          xs[2 * s + 1][b] = *reinterpret_cast<const float*>(xbase[b] + off + 64);
+          const uint32_t off = XB * (32u * (uint32_t)uu + i16);
+          xs[2 * s][b] = (float)*reinterpret_cast<const XT*>(xbase[b] + off);
+          xs[2 * s + 1][b] = (float)*reinterpret_cast<const XT*>(xbase[b] + off + 16 * XB);
         }
       }
     }
@@ -381,6 +444,10 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
       for (int i = 0; i < RPW; ++i) ev[i] = src[2 * (st_h * RPW + i) + (lane >> 5)];
     }
   }
+  // fused linear: the first 64 top-X column indices go out first (consumed right after the
+  // staging barrier, while the weight loads behind them are still in flight)
+  int topx_idx = -1;
+  if (lin && lin->full_rows) topx_idx = lin->full_idx[lane < lin->gm.topX ? lane : lin->gm.topX - 1];
   u32x4 w0[NBUF][R];
   float x0[NXR][BT];
   load_chunk(u_wave, w0, x0);
@@ -390,6 +457,8 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
 
   constexpr int kCodebookFloats = 4 * SUBB / 4;  // the four column sub-tables
   if (tid == 0) *reinterpret_cast<unsigned*>(lds + kCodebookFloats + WAVES * BT * kTileN) = 0u;  // epilogue ticket
+  float* topx_sum = lds + kCodebookFloats + WAVES * BT * kTileN + 4;  // [BT][64], fused linear only
+  if (lin && tid < BT * kTileN) topx_sum[tid] = 0.f;
   // ---- stage the codebooks (row-wise, see above) ----
   if constexpr (!(ABL & 4)) {
     if constexpr (BITS == 4) {
@@ -437,6 +506,34 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
       }
     }
   };
+
+  // ---- fused linear: top-X rows whose column lies in this tile are this workgroup's job too --
+  // their dot product over this K slice joins the column's partial sum, so they need no role, no
+  // atomics and no counting of their own.  Every wave scans the indices itself (no barrier); a
+  // match is rare (topX columns out of N), and its loads overlap the first chunk's.
+  if (lin && lin->full_rows) {
+    const int topX = lin->gm.topX;
+    const int k_beg = u_beg * F::kK, k_end = u_end * F::kK;
+    for (int j0 = 0; j0 < topX; j0 += 64) {
+      const int cj = (j0 == 0) ? topx_idx : lin->full_idx[j0 + lane < topX ? j0 + lane : topX - 1];
+      unsigned long long m = __ballot(j0 + lane < topX && cj >= col0 && cj < col0 + kTileN);
+      while (m) {
+        const int jl = __builtin_ctzll(m);
+        m &= m - 1;
+        const int j = j0 + jl;
+        const int cc = __builtin_amdgcn_readlane(cj, jl) - col0;
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+          float p = 0.f;
+          for (int k = k_beg + wave * 64 + lane; k < k_end; k += WAVES * 64)
+            p = __builtin_fmaf(lin->full_rows[(size_t)k * topX + j],
+                               (float)x[(size_t)(b0 + (b < nb ? b : nb - 1)) * K + k], p);
+          p = wave_sum(p);
+          if (lane == 0) atomicAdd(topx_sum + b * kTileN + cc, p);
+        }
+      }
+    }
+  }
 
   decode_chunk(u_wave, w0, x0);
   for (int u0 = u_wave + NBUF * STEP; u0 < u_end; u0 += NBUF * STEP) {  // scalar loop
@@ -498,13 +595,33 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   const int c = col0 + lane;
   if (c < N) {
+    u64 total[BT];
+    unsigned target = 0;
+    if (lin) {  // contributions this column receives: K slices + the CSR chunks its row is spread over
+      target = (unsigned)lin->gm.k_slices;
+      if (lin->gm.csr_blocks) target += (unsigned)csr_chunks_of_row(lin->rows[c], lin->rows[c + 1]);
+    }
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
       if (b < nb) {
         float sum = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) sum += red[(w * BT + b) * kTileN + lane];
-        atomicAdd(y + (size_t)(b0 + b) * N + c, sum);
+        const size_t at = (size_t)(b0 + b) * N + c;
+        if (lin) {
+          if (lin->full_rows) sum += topx_sum[b * kTileN + lane];
+          const u64 mine = kCountUnit + to_fixed(sum);
+          total[b] = atomicAdd(reinterpret_cast<u64*>(y) + at, mine) + mine;
+        } else {
+          atomicAdd(y + at, sum);
+        }
+      }
+    }
+    if (lin) {  // all the round trips are in flight before the first result is looked at
+#pragma unroll
+      for (int b = 0; b < BT; ++b) {
+        const size_t at = (size_t)(b0 + b) * N + c;
+        if (b < nb) column_done(*lin, reinterpret_cast<u64*>(y) + at, total[b], target, at, c);
       }
     }
   }
@@ -525,11 +642,12 @@ __device__ __forceinline__ void dense_role(const float* x, const u32x4* q, float
 //   then, LDS only: each non-zero finds its row by binary search in the staged pointers, products
 //   are summed per row in LDS, and each touched row leaves as one atomic.
 // ------------------------------------------------------------------------------------------------
-template <int T>
-__device__ __forceinline__ void csr_role(const float* x, float* __restrict__ y,
+template <int T, typename XT, typename AT>
+__device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
                                          const int* __restrict__ rows, const int* __restrict__ cols,
                                          const float* __restrict__ vals, int nnz, int K, int N, int b0,
-                                         int nb, int chunk, float* lds) {
+                                         int nb, int chunk, float* lds, const Segment* lin) {
+  constexpr bool LIN = sizeof(AT) == 8;
   const int tid = threadIdx.x;
   const int e0 = chunk * kCsrChunk;
   int e1 = e0 + kCsrChunk;
@@ -566,7 +684,7 @@ __device__ __forceinline__ void csr_role(const float* x, float* __restrict__ y,
     for (int i = tid; i < n; i += T) srows[i] = rows[c_lo + i];
   float xg[EPT];
 #pragma unroll
-  for (int i = 0; i < EPT; ++i) xg[i] = x[(size_t)b0 * K + col[i]];  // first batch row's gather
+  for (int i = 0; i < EPT; ++i) xg[i] = (float)x[(size_t)b0 * K + col[i]];  // first batch row's gather
   __syncthreads();
 
   // local row of each non-zero: largest i with rows[c_lo + i] <= e
@@ -591,14 +709,14 @@ __device__ __forceinline__ void csr_role(const float* x, float* __restrict__ y,
   }
 
   for (int b = 0; b < nb; ++b) {
-    float* yb = y + (size_t)(b0 + b) * N + c_lo;
+    AT* yb = y + (size_t)(b0 + b) * N + c_lo;
     if (in_lds) {
       for (int i = tid; i < n; i += T) sacc[i] = 0.f;
       __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-      const float xv = (b == 0) ? xg[i] : x[(size_t)(b0 + b) * K + col[i]];
+      const float xv = (b == 0) ? xg[i] : (float)x[(size_t)(b0 + b) * K + col[i]];
       const float p = val[i] * xv;
       const int r = lr[i];
       // a wave holds 64 consecutive non-zeros: inside a long row they all share the row, so
@@ -607,19 +725,41 @@ __device__ __forceinline__ void csr_role(const float* x, float* __restrict__ y,
       if (__all(r == r_first)) {
         const float sum = wave_sum(p);
         if ((tid & 63) == 0 && r_first >= 0) {
-          if (in_lds) atomicAdd(sacc + r_first, sum); else atomicAdd(yb + r_first, sum);
+          if (in_lds) atomicAdd(sacc + r_first, sum); else acc_add(yb + r_first, sum);
         }
       } else if (r >= 0) {
-        if (in_lds) atomicAdd(sacc + r, p); else atomicAdd(yb + r, p);
+        if (in_lds) atomicAdd(sacc + r, p); else acc_add(yb + r, p);
       }
     }
     if (in_lds) {
       __syncthreads();
       for (int i = tid; i < n - 1; i += T) {
         const float sum = sacc[i];
-        if (sum != 0.f) atomicAdd(yb + i, sum);
+        if constexpr (LIN) {
+          // one COUNTED contribution per row this chunk holds a part of, whatever its value
+          const int r0 = srows[i], r1 = srows[i + 1];
+          if ((r0 > e0 ? r0 : e0) < (r1 < e1 ? r1 : e1)) {
+            const u64 mine = kCountUnit + to_fixed(sum);
+            const unsigned target = (unsigned)lin->gm.k_slices + (unsigned)csr_chunks_of_row(r0, r1);
+            column_done(*lin, yb + i, atomicAdd(yb + i, mine) + mine, target, (size_t)(b0 + b) * N + c_lo + i, c_lo + i);
+          }
+        } else {
+          if (sum != 0.f) acc_add(yb + i, sum);
+        }
       }
       __syncthreads();
+    } else if constexpr (LIN) {
+      // the values went in uncounted, one add per non-zero; once they are acknowledged, count
+      // this chunk on every row it holds a part of
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      for (int i = tid; i < n - 1; i += T) {
+        const int r0 = rows[c_lo + i], r1 = rows[c_lo + i + 1];
+        if ((r0 > e0 ? r0 : e0) < (r1 < e1 ? r1 : e1)) {
+          const unsigned target = (unsigned)lin->gm.k_slices + (unsigned)csr_chunks_of_row(r0, r1);
+          column_done(*lin, yb + i, atomicAdd(yb + i, kCountUnit) + kCountUnit, target, (size_t)(b0 + b) * N + c_lo + i, c_lo + i);
+        }
+      }
     }
   }
 }
@@ -629,8 +769,8 @@ __device__ __forceinline__ void csr_role(const float* x, float* __restrict__ y,
 // i.e. one contiguous slab of kTopxRows*topX floats, and streams it coalesced (the reference keeps
 // topX of 128 lanes busy with stride-topX reads, quant_cuda_kernel.cu:1113-1118).
 // ------------------------------------------------------------------------------------------------
-template <int T>
-__device__ __forceinline__ void topx_role(const float* x, float* __restrict__ y,
+template <int T, typename XT, typename AT>
+__device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
                                           const float* __restrict__ full_rows,
                                           const int* __restrict__ full_idx, int topX, int K, int N,
                                           int b0, int nb, int slab, float* lds) {
@@ -643,8 +783,8 @@ __device__ __forceinline__ void topx_role(const float* x, float* __restrict__ y,
   const bool in_lds = topX <= kTopxLds;
   float* sacc = lds;
   for (int b = 0; b < nb; ++b) {
-    const float* xb = x + (size_t)(b0 + b) * K + k0;
-    float* yb = y + (size_t)(b0 + b) * N;
+    const XT* xb = x + (size_t)(b0 + b) * K + k0;
+    AT* yb = y + (size_t)(b0 + b) * N;
     if (in_lds) {
       for (int c = tid; c < topX; c += T) sacc[c] = 0.f;
       __syncthreads();
@@ -652,12 +792,12 @@ __device__ __forceinline__ void topx_role(const float* x, float* __restrict__ y,
     for (int e = tid; e < nel; e += T) {
       const int kk = e / topX;
       const int c = e - kk * topX;
-      const float p = fr[e] * xb[kk];
-      if (in_lds) atomicAdd(sacc + c, p); else atomicAdd(yb + full_idx[c], p);
+      const float p = fr[e] * (float)xb[kk];
+      if (in_lds) atomicAdd(sacc + c, p); else acc_add(yb + full_idx[c], p);
     }
     if (in_lds) {
       __syncthreads();
-      for (int c = tid; c < topX; c += T) atomicAdd(yb + full_idx[c], sacc[c]);
+      for (int c = tid; c < topX; c += T) acc_add(yb + full_idx[c], sacc[c]);
       __syncthreads();
     }
   }
@@ -666,14 +806,17 @@ __device__ __forceinline__ void topx_role(const float* x, float* __restrict__ y,
 // ------------------------------------------------------------------------------------------------
 // the fused kernel
 // ------------------------------------------------------------------------------------------------
-template <int BITS, int BT, int WAVES, int ABL = 0>
+template <int BITS, int BT, int WAVES, int ABL, bool LIN>
 // occupancy target: 2 workgroups of 8 waves per CU (<= 128 VGPRs); the 3-bit kernels with a wide
 // batch tile need more registers and settle for one workgroup per CU rather than spill
 __global__ void __launch_bounds__(WAVES * 64, (ABL & 64) ? 8 : (BITS == 3 && BT >= 4) ? 2 : 4)
-sqllm_fused_matvec(const float* x, const GroupArgs ga) {
+sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
   constexpr int T = WAVES * 64;
   constexpr int kLds = lds_floats(Fmt<BITS>::kLut, WAVES, BT);
   __shared__ __attribute__((aligned(16))) float lds[kLds];
+  using XT = typename XType<LIN>::type;
+  using AT = typename AccType<LIN>::type;
+  const XT* x = reinterpret_cast<const XT*>(xv);
 
   // which op of the launch this workgroup belongs to (wave-uniform; 1 segment = a plain op)
   int s = 0;
@@ -697,12 +840,14 @@ sqllm_fused_matvec(const float* x, const GroupArgs ga) {
     sp = bid < gm.dense_block0 ? bid : -1;
   }
   if (d >= 0 && d < gm.dense_blocks) {
-    dense_role<BITS, BT, WAVES, ABL>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, b0, nb,
-                                     d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds);
+    dense_role<BITS, BT, WAVES, ABL, XT>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, b0, nb,
+                                         d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds, LIN ? &sg : nullptr);
   } else if (sp >= 0 && sp < gm.csr_blocks) {
-    csr_role<T>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds);
+    csr_role<T, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds,
+                        LIN ? &sg : nullptr);
   } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
-    topx_role<T>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, b0, nb, sp - gm.csr_blocks, lds);
+    // (never taken by fused-linear launches: their plan has no top-X workgroups)
+    topx_role<T, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, b0, nb, sp - gm.csr_blocks, lds);
   }
 }
 
@@ -790,11 +935,11 @@ static hipError_t launch_calib(const LaunchArgs& a, hipStream_t stream) {
 }
 #endif
 
-template <int BITS, int BT, int WAVES, int ABL = 0>
+template <int BITS, int BT, int WAVES, int ABL = 0, bool LIN = false>
 static hipError_t launch_inst(const LaunchArgs& a, hipStream_t stream) {
   const int batch = a.ga.seg[0].gm.batch;
   dim3 grid(a.ga.block0[a.ga.n_seg], (batch + BT - 1) / BT);
-  auto kern = sqllm_fused_matvec<BITS, BT, WAVES, ABL>;
+  auto kern = sqllm_fused_matvec<BITS, BT, WAVES, ABL, LIN>;
   if (a.ev_start || a.ev_stop) {
     // same kernel, with the dispatch's own begin/end timestamps exposed through two events
     hipExtLaunchKernelGGL(kern, grid, dim3(WAVES * 64), 0, stream, a.ev_start, a.ev_stop, 0, a.x, a.ga);
@@ -804,20 +949,20 @@ static hipError_t launch_inst(const LaunchArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <int BITS>
+template <int BITS, bool LIN>
 static hipError_t launch_bt(const LaunchArgs& a, hipStream_t stream) {
   switch (batch_tile(a.ga.seg[0].gm.batch)) {
-    case 1: return launch_inst<BITS, 1, kWaves>(a, stream);
-    case 2: return launch_inst<BITS, 2, kWaves>(a, stream);
-    case 4: return launch_inst<BITS, 4, kWaves>(a, stream);
-    default: return launch_inst<BITS, 8, kWaves>(a, stream);
+    case 1: return launch_inst<BITS, 1, kWaves, 0, LIN>(a, stream);
+    case 2: return launch_inst<BITS, 2, kWaves, 0, LIN>(a, stream);
+    case 4: return launch_inst<BITS, 4, kWaves, 0, LIN>(a, stream);
+    default: return launch_inst<BITS, 8, kWaves, 0, LIN>(a, stream);
   }
 }
 
 hipError_t launch_fused(int bits, const LaunchArgs& a, hipStream_t stream) {
 #ifdef SQLLM_ABLATION_BUILD
   if (a.ablate >= 100) return launch_calib(a, stream);
-  if (bits == 4 && batch_tile(a.ga.seg[0].gm.batch) == 1 && a.ablate) {
+  if (!a.linear && bits == 4 && batch_tile(a.ga.seg[0].gm.batch) == 1 && a.ablate) {
     switch (a.ablate) {
       case 1: return launch_inst<4, 1, kWaves, 1>(a, stream);
       case 2: return launch_inst<4, 1, kWaves, 2>(a, stream);
@@ -832,7 +977,8 @@ hipError_t launch_fused(int bits, const LaunchArgs& a, hipStream_t stream) {
     }
   }
 #endif
-  return bits == 4 ? launch_bt<4>(a, stream) : launch_bt<3>(a, stream);
+  if (a.linear) return bits == 4 ? launch_bt<4, true>(a, stream) : launch_bt<3, true>(a, stream);
+  return bits == 4 ? launch_bt<4, false>(a, stream) : launch_bt<3, false>(a, stream);
 }
 
 }  // namespace sqllm

@@ -6,6 +6,9 @@ below an eager launch (~3-4 us of host time).  `OpSequence` pre-marshals every o
 C array of `sqllm_op` descriptors (include/sqllm_hip.h) and then
   * `launch()`  enqueues the whole pass through one FFI crossing (sqllm_launch_sequence), or
   * `graph()`   captures that into a HIP graph for replay.
+With `linear=True` the ops are fused linears (sqllm_linear_f16): fp16 activations in, fp16 out,
+bias included, no zero-fill / cast launches around them -- the whole matvec branch of
+QuantLinearLUT.forward (squeezellm/quant.py:211-312) per kernel.
 All launches go to torch's current stream; nothing here synchronises.
 """
 from __future__ import annotations
@@ -24,18 +27,27 @@ def _ptr(t):
 class OpSequence:
     """A fixed list of ops `ys[i] += layer_i(xs[i])` with all pointers resolved up front."""
 
-    def __init__(self, layers, xs, ys, batched: bool = False, fuse_shared_input: bool = False):
+    def __init__(self, layers, xs, ys, batched: bool = False, fuse_shared_input: bool = False,
+                 linear: bool = False):
         """fuse_shared_input: consecutive ops that read the SAME x tensor (and agree in K, bits,
         batch) are enqueued as one kernel (sqllm_launch_group), up to 4 per launch -- q/k/v and
-        gate/up of a decoder layer."""
+        gate/up of a decoder layer.
+        linear: `ys[i] = fp16(layer_i(xs[i]) + bias_i)` with fp16 xs / ys (ys overwritten) instead
+        of the operator semantics `ys[i] += layer_i(xs[i])` on fp32."""
         if not (len(layers) == len(xs) == len(ys)):
             raise ValueError("layers, xs, ys must have equal length")
         self.n = len(layers)
-        self._keep = (layers, xs, ys)  # keep the tensors alive as long as the descriptors
-        self.ops = (_lib.SqllmOp * self.n)()
+        self.linear = bool(linear)
+        self._keep = [layers, xs, ys]  # keep the tensors alive as long as the descriptors
         self.device = xs[0].device if self.n else torch.device("cuda")
+        io = torch.float16 if linear else torch.float32
+        if linear:
+            self.lins = (_lib.SqllmLinear * self.n)()
+            self.ops = [self.lins[i].op for i in range(self.n)]
+        else:
+            self.ops = (_lib.SqllmOp * self.n)()
         for i, (lay, x, y) in enumerate(zip(layers, xs, ys)):
-            for name, t, dt in (("x", x, torch.float32), ("y", y, torch.float32),
+            for name, t, dt in (("x", x, io), ("y", y, io),
                                 ("qweight", lay["qweight"], torch.int32),
                                 ("lookup_table", lay["lookup_table"], torch.float32)):
                 if t.dtype != dt or not t.is_cuda or not t.is_contiguous():
@@ -53,6 +65,14 @@ class OpSequence:
             if lay.get("full_rows") is not None:
                 o.full_rows, o.full_row_indices = _ptr(lay["full_rows"]), _ptr(lay["full_row_indices"])
                 o.topX = lay["full_rows"].shape[1]
+            if linear:
+                bias = lay.get("bias")
+                if bias is not None and (bias.dtype != torch.float32 or not bias.is_cuda or bias.numel() != N):
+                    raise ValueError(f"op {i}: bias must be an fp32 GPU tensor of {N} elements")
+                ws = torch.zeros(_lib.linear_workspace_bytes(N, batch), dtype=torch.uint8, device=self.device)
+                self._keep.append(ws)
+                self.lins[i].bias = _ptr(bias)
+                self.lins[i].workspace = ws.data_ptr()
         # launch groups: lists of consecutive op indices sharing one input vector
         self.groups = []
         for i in range(self.n):
@@ -71,9 +91,12 @@ class OpSequence:
     def launch(self) -> None:
         """Enqueue the whole pass on the current stream of the sequence's device (one FFI crossing)."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self._lib.sqllm_launch_groups(self.ops, self._sizes, self.n_groups, stream, ctypes.byref(self._done))
+        if self.linear:
+            rc = self._lib.sqllm_linear_f16_groups(self.lins, self._sizes, self.n_groups, stream, ctypes.byref(self._done))
+        else:
+            rc = self._lib.sqllm_launch_groups(self.ops, self._sizes, self.n_groups, stream, ctypes.byref(self._done))
         if rc != 0:
-            _lib.check(rc, f"sqllm_launch_groups (group {self._done.value} of {self.n_groups})")
+            _lib.check(rc, f"launch of group {self._done.value} of {self.n_groups}")
 
     def profile(self, reps: int = 3):
         """Per-LAUNCH kernel durations in microseconds (device-side begin->end of each dispatch, as
@@ -81,6 +104,8 @@ class OpSequence:
         passes.  Synchronises."""
         import numpy as np
 
+        if self.linear:
+            raise NotImplementedError("per-launch profiling is provided for operator sequences only")
         out = (ctypes.c_float * max(self.n_groups, 1))()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self._lib.sqllm_profile_groups(self.ops, self._sizes, self.n_groups, stream, int(reps), out)

@@ -11,12 +11,13 @@ format restatement used by the tests.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 
 import torch
 import torch.nn as nn
 
-from . import quant_cuda
+from . import _lib, quant_cuda
 
 
 class QuantLinearLUT(nn.Module):
@@ -112,6 +113,61 @@ class QuantLinearLUT(nn.Module):
         if topX:
             m.full_rows, m.full_row_indices = layer["full_rows"], layer["full_row_indices"]
         return m
+
+
+class QuantLinearLUTFused(QuantLinearLUT):
+    """Opt-in forward for fp16 activations: ONE kernel per call (sqllm_linear_f16) instead of the
+    reference's four (`zeros`/`bias.clone()`, `x.float()`, the op, `y.to(fp16)`; quant.py:214-223,
+    :311-312 and :314-321, :380-383).  Same buffers and state dict as QuantLinearLUT -- switch an
+    existing model over with `fuse_quant_lut(model)`.  Result = fp16(fp32 accumulation + bias);
+    the reference's batched branch rounds to fp16 before adding the bias (and then promotes to
+    fp32), so the two differ by at most one fp16 rounding of the output.  Other dtypes take the
+    parent's path."""
+
+    def _workspace(self, batch: int, device) -> torch.Tensor:
+        cache = self.__dict__.setdefault("_ws", {})
+        key = (batch, device)
+        if key not in cache:  # zero-filled once; every launch leaves it zero-filled
+            cache[key] = torch.zeros(_lib.linear_workspace_bytes(self.outfeatures, batch), dtype=torch.uint8, device=device)
+        return cache[key]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dtype != torch.float16 or not x.is_cuda:
+            return super().forward(x)
+        K, N = self.infeatures, self.outfeatures
+        if x.shape[-1] != K:
+            raise ValueError(f"last dimension of x must be {K}, got {tuple(x.shape)}")
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        batch = 0 if rows == 1 else rows
+        out = torch.empty((rows, N), dtype=torch.float16, device=x.device)
+        lin = _lib.SqllmLinear()
+        o = lin.op
+        o.bits, o.batch, o.K, o.N = self.bits, batch, K, N
+        o.vec, o.qweight, o.mul, o.lookup_table = x2.data_ptr(), self.qweight.data_ptr(), out.data_ptr(), self.lookup_table.data_ptr()
+        if self.include_sparse and self.numvals > 0:
+            o.rows, o.cols, o.vals, o.nnz = self.rows.data_ptr(), self.cols.data_ptr(), self.vals.data_ptr(), self.vals.numel()
+            if self.topX > 0:
+                o.full_rows, o.full_row_indices, o.topX = self.full_rows.data_ptr(), self.full_row_indices.data_ptr(), self.topX
+        lin.bias = None if self.bias is None else self.bias.data_ptr()
+        lin.workspace = self._workspace(batch, x.device).data_ptr()
+        with quant_cuda._on_device_of(x) as stream:
+            rc = _lib.load().sqllm_linear_f16(ctypes.byref(lin), stream)
+        _lib.check(rc, "sqllm_linear_f16")
+        return out.reshape(*x.shape[:-1], N)
+
+
+def fuse_quant_lut(module: nn.Module) -> int:
+    """Switch every QuantLinearLUT under `module` to the fused fp16 forward (in place, buffers and
+    state dict untouched).  Returns the number of layers switched."""
+    n = 0
+    for m in module.modules():
+        if type(m) is QuantLinearLUT:
+            m.__class__ = QuantLinearLUTFused
+            n += 1
+    return n
 
 
 def make_quant_lut(module, names, bits, name="", include_sparse=False, numvals=None, topX=0, balanced=False,

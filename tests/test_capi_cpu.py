@@ -115,6 +115,32 @@ def test_launch_rejects_bad_arguments_before_touching_the_device():
     assert lib.sqllm_launch_sequence(None, 0, None, ctypes.byref(n_done)) == 0 and n_done.value == 0
 
 
+def test_linear_entry_points_validate_and_size_their_workspace():
+    from squeezellm_amd import _lib
+
+    lib = _lib.load()
+    # 64-bit accumulator words [batch, N]
+    assert _lib.linear_workspace_bytes(4096, 0) == 8 * 4096
+    assert _lib.linear_workspace_bytes(456, 5) == 8 * 5 * 456
+    lin = _lib.SqllmLinear()
+    lin.op.bits, lin.op.K, lin.op.N = 4, 128, 128
+    lin.op.vec = lin.op.qweight = lin.op.mul = lin.op.lookup_table = 16
+    assert lib.sqllm_linear_f16(None, None) == -3
+    assert lib.sqllm_linear_f16(ctypes.byref(lin), None) == -3  # no workspace
+    lin.workspace = 8
+    assert lib.sqllm_linear_f16(ctypes.byref(lin), None) == -4  # workspace not 16-byte aligned
+    lin.workspace, lin.op.bits = 16, 2
+    assert lib.sqllm_linear_f16(ctypes.byref(lin), None) == -1
+    sizes = (ctypes.c_int32 * 1)(0)
+    done = ctypes.c_int32(-1)
+    assert lib.sqllm_linear_f16_groups(ctypes.byref(lin), sizes, 1, None, ctypes.byref(done)) == -8 and done.value == 0
+    assert lib.sqllm_linear_f16_groups(None, None, 0, None, None) == 0
+    # the operator entry points refuse matrices their 32-bit offsets cannot address
+    op = _lib.SqllmOp(bits=4, batch=0, K=65536, N=131072)
+    op.vec = op.qweight = op.mul = op.lookup_table = 16
+    assert lib.sqllm_launch(ctypes.byref(op), None) == -2
+
+
 def test_no_cpu_fallback_in_the_operator_module():
     import torch
 

@@ -1,0 +1,205 @@
+"""GPU tests of the fused linear (sqllm_linear_f16): fp16 in / fp16 out, bias, self-cleaning
+workspace.  Checked against the oracle's fp64 matvec on the same fp16-rounded activations; the
+result must equal the exact value rounded to fp16 up to a few fp32 accumulation ulps, i.e. within
+one fp16 ulp of it."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _npl(lay):
+    import torch
+
+    return {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in lay.items()}
+
+
+def _exact(npl, x16, kind):
+    """fp64 result of the three terms + bias for fp16 activations x16 [rows, K]."""
+    x = x16.astype(np.float64)
+    ref = H.oracle_ref(npl, x if x.shape[0] > 1 else x[0], np.zeros((x.shape[0], npl["N"])) if x.shape[0] > 1 else np.zeros(npl["N"]), kind)
+    ref = np.asarray(ref, np.float64).reshape(x.shape[0], npl["N"])
+    if npl.get("bias") is not None:
+        ref = ref + npl["bias"].astype(np.float64)
+    return ref
+
+
+def _check_fp16(got16, exact):
+    got = got16.astype(np.float64)
+    # one fp16 ulp at the magnitude of each element (fp16 has 11 significant bits) + tiny absolute slack
+    tol = np.maximum(np.abs(exact), 2.0**-14) * 2.0**-10 + 1e-6
+    bad = np.abs(got - exact) > tol
+    assert not bad.any(), f"{bad.sum()} of {bad.size} outputs off by more than 1 fp16 ulp; worst {np.abs(got - exact).max()}"
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("kind", ["dense", "spmv", "hybrid"])
+@pytest.mark.parametrize("rows", [1, 2, 5, 8, 19])
+@pytest.mark.parametrize("bias", [False, True])
+def test_fused_forward_matches_oracle_and_cleans_up(gpu, bits, kind, rows, bias):
+    import torch
+
+    from squeezellm_amd import quant, synth
+
+    K, N = 1024, 456  # ragged last column tile (456 = 7 * 64 + 8)
+    lay = synth.make_layer(K, N, bits, sparse_frac=0.0 if kind == "dense" else 0.01, topX=3 if kind == "hybrid" else 0,
+                           heavy_rows=2 if kind != "dense" else 0, bias=bias, device=gpu, seed=31 * bits + rows)
+    mod = quant.QuantLinearLUT.from_operands(lay)
+    assert quant.fuse_quant_lut(mod) == 1 and type(mod) is quant.QuantLinearLUTFused
+    g = torch.Generator(device=gpu).manual_seed(rows)
+    x = torch.randn((rows, K), device=gpu, generator=g).half()
+    npl = _npl(lay)
+    exact = _exact(npl, x.cpu().numpy(), kind)
+    for rep in range(3):  # the second and third call run on the workspace the previous one left behind
+        y = mod(x if rows > 1 else x.reshape(1, 1, K))
+        assert y.dtype == torch.float16 and y.shape[-1] == N
+        _check_fp16(y.reshape(rows, N).cpu().numpy(), exact)
+    ws = next(iter(mod._ws.values()))
+    assert int(ws.count_nonzero()) == 0, "workspace must be left zero-filled"
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+def test_fused_forward_equals_the_four_launch_path(gpu, bits):
+    """Same layer through QuantLinearLUT.forward (zeros + float + op + cast) and through the fused
+    kernel: both are fp16 roundings of fp32 sums of the same terms (summation order differs)."""
+    import torch
+
+    from squeezellm_amd import quant, synth
+
+    K, N = 4096, 4096
+    lay = synth.make_layer(K, N, bits, sparse_frac=0.0045, topX=10, heavy_rows=10, device=gpu, seed=5)
+    ref_mod = quant.QuantLinearLUT.from_operands(lay)
+    fused = quant.QuantLinearLUT.from_operands(lay)
+    fused.__class__ = quant.QuantLinearLUTFused
+    x = torch.randn((1, 1, K), device=gpu).half()
+    a, b = ref_mod(x).float(), fused(x).float()
+    assert a.shape == b.shape
+    assert float((a - b).abs().max()) <= 2.0**-10 * float(a.abs().max()) * 1.01
+
+
+def test_fuse_quant_lut_switches_children(gpu):
+    import torch
+
+    from squeezellm_amd import quant, synth
+
+    lays = [synth.make_layer(256, 128, 4, device=gpu, seed=s) for s in range(2)]
+    model = torch.nn.Sequential(*[quant.QuantLinearLUT.from_operands(l) for l in lays])
+    keys = list(model.state_dict().keys())
+    assert quant.fuse_quant_lut(model) == 2 and list(model.state_dict().keys()) == keys
+    x = torch.randn((1, 256), device=gpu).half()
+    y = model[0](x)
+    assert y.dtype == torch.float16 and y.shape == (1, 128)
+    # fp32 activations keep the operator path
+    assert model[0](x.float()).dtype == torch.float32
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("batched", [False, True])
+def test_linear_sequence_groups_and_graph(gpu, bits, batched):
+    """A decoder layer's seven linears as fused-linear groups (q/k/v and gate/up share a launch),
+    eager and replayed from a HIP graph."""
+    import torch
+
+    from squeezellm_amd import decode, synth
+
+    hidden, inter, B = 512, 1408, 4
+    shapes = [(hidden, hidden)] * 4 + [(hidden, inter)] * 2 + [(inter, hidden)]
+    lays = [synth.make_layer(K, N, bits, sparse_frac=0.005, topX=2, heavy_rows=1, bias=(i % 2 == 0), device=gpu, seed=i)
+            for i, (K, N) in enumerate(shapes)]
+    rows = B if batched else 1
+    xh = torch.randn((rows, hidden), device=gpu).half()
+    xi = torch.randn((rows, inter), device=gpu).half()
+    xo = torch.randn((rows, hidden), device=gpu).half()
+    xs = [xh, xh, xh, xo, xh, xh, xi]
+    ys = [torch.full((rows, N), 7.0, device=gpu, dtype=torch.float16) for _, N in shapes]  # must be overwritten
+    seq = decode.OpSequence(lays, xs, ys, batched=batched, fuse_shared_input=True, linear=True)
+    assert [len(g) for g in seq.groups] == [3, 1, 2, 1]
+    exact = [_exact(_npl(l), x.cpu().numpy(), "hybrid") for l, x in zip(lays, xs)]
+    seq.launch()
+    torch.cuda.synchronize()
+    for y, e in zip(ys, exact):
+        _check_fp16(y.cpu().numpy(), e)
+    g = seq.graph()
+    for y in ys:
+        y.fill_(-3.0)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    for y, e in zip(ys, exact):
+        _check_fp16(y.cpu().numpy(), e)
+    with pytest.raises(NotImplementedError):
+        seq.profile()
+
+
+def test_linear_full_size_hybrid_w3(gpu):
+    """LLaMA-7B down_proj shape (K = 11008), w3 s45 + top-X, through the C ABI directly."""
+    import torch
+
+    from squeezellm_amd import _lib, synth
+
+    K, N = 11008, 4096
+    lay = synth.make_layer(K, N, 3, sparse_frac=0.0045, topX=10, heavy_rows=10, bias=True, device=gpu, seed=9)
+    x = torch.randn(K, device=gpu).half()
+    out = torch.empty(N, device=gpu, dtype=torch.float16)
+    ws = torch.zeros(_lib.linear_workspace_bytes(N, 0), dtype=torch.uint8, device=gpu)
+    lin = _lib.SqllmLinear()
+    o = lin.op
+    o.bits, o.batch, o.K, o.N = 3, 0, K, N
+    o.vec, o.qweight, o.mul, o.lookup_table = x.data_ptr(), lay["qweight"].data_ptr(), out.data_ptr(), lay["lookup_table"].data_ptr()
+    o.rows, o.cols, o.vals, o.nnz = lay["rows"].data_ptr(), lay["cols"].data_ptr(), lay["vals"].data_ptr(), lay["vals"].numel()
+    o.full_rows, o.full_row_indices, o.topX = lay["full_rows"].data_ptr(), lay["full_row_indices"].data_ptr(), 10
+    lin.bias, lin.workspace = lay["bias"].data_ptr(), ws.data_ptr()
+    lib = _lib.load()
+    exact = _exact(_npl(lay), x.cpu().numpy().reshape(1, K), "hybrid")
+    for _ in range(2):
+        assert lib.sqllm_linear_f16(ctypes.byref(lin), torch.cuda.current_stream().cuda_stream) == 0
+        torch.cuda.synchronize()
+        _check_fp16(out.cpu().numpy().reshape(1, N), exact)
+    assert int(ws.count_nonzero()) == 0
+    # rejected arguments enqueue nothing
+    lin.workspace = None
+    assert lib.sqllm_linear_f16(ctypes.byref(lin), None) == -3
+    lin.workspace = ws.data_ptr() + 4
+    assert lib.sqllm_linear_f16(ctypes.byref(lin), None) == -4
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("rows", [1, 3])
+def test_linear_counts_every_kind_of_sparse_contribution(gpu, bits, rows):
+    """Shapes chosen so that completion counting sees every case: rows spread over several CSR
+    chunks (heavy rows), chunks that span more rows than fit in LDS (very sparse region, uncounted
+    adds + a counting pass), empty rows, more than 64 top-X columns, and repeated top-X indices."""
+    import torch
+
+    from squeezellm_amd import quant, synth
+
+    K, N = 512, 8192
+    lay = synth.make_layer(K, N, bits, sparse_frac=1.0 / (4 * K), topX=70, heavy_rows=3, heavy_frac=0.9,
+                           bias=True, device=gpu, seed=77 + bits)
+    # rows 100..5000 get no outliers at all except three heavy ones -> one chunk spans > 2048 rows
+    r = lay["rows"].cpu().numpy().astype(np.int64)
+    cnt = np.diff(r)
+    keep = np.ones(N, bool)
+    keep[100:5000] = cnt[100:5000] > 100
+    sel = np.repeat(keep, cnt)
+    lay["cols"] = lay["cols"][torch.from_numpy(sel).to(gpu)].contiguous()
+    lay["vals"] = lay["vals"][torch.from_numpy(sel).to(gpu)].contiguous()
+    new_r = np.zeros(N + 1, np.int32)
+    new_r[1:] = np.cumsum(np.where(keep, cnt, 0))
+    lay["rows"] = torch.from_numpy(new_r).to(gpu)
+    assert int(new_r[-1]) == lay["vals"].numel()
+    fi = lay["full_row_indices"].clone()
+    fi[1] = fi[0]  # the same column twice
+    fi[69] = N - 1
+    lay["full_row_indices"] = fi
+    mod = quant.QuantLinearLUT.from_operands(lay)
+    mod.__class__ = quant.QuantLinearLUTFused
+    x = torch.randn((rows, K), device=gpu).half()
+    exact = _exact(_npl(lay), x.cpu().numpy(), "hybrid")
+    for _ in range(2):
+        _check_fp16(mod(x).reshape(rows, N).cpu().numpy(), exact)
+    assert int(next(iter(mod._ws.values())).count_nonzero()) == 0

@@ -187,3 +187,32 @@ def test_grouped_launch_same_input(gpu, bits, batched):
     bad = (_lib.SqllmOp * 2)(seq1.ops[0], seq1.ops[4])
     assert lib.sqllm_launch_group(bad, 2, None) == -8
     assert lib.sqllm_launch_group(seq1.ops, 0, None) == -8 and lib.sqllm_launch_group(seq1.ops, 5, None) == -8
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+def test_gpu_packed_layer_runs_through_the_module(gpu, bits):
+    """pack.pack_layer on device tensors -> QuantLinearLUT -> hybrid op; reference result is the
+    fp64 product with the effective weight lut[idx] + (outlier - zero centroid)."""
+    import torch
+
+    from squeezellm_amd import pack
+    from squeezellm_amd.quant import QuantLinearLUT
+
+    N, K, topX = 512, 1024, 10
+    rng = np.random.default_rng(100 + bits)
+    idx_nk = rng.integers(0, 1 << bits, size=(N, K))
+    lut = np.sort(rng.normal(0, 0.02, (N, 1 << bits)).astype(np.float32), axis=1)
+    outl = np.where(rng.random((N, K)) < 0.005, rng.normal(0, 0.2, (N, K)), 0).astype(np.float32)
+    outl[[5, 99]] = rng.normal(0, 0.2, (2, K)).astype(np.float32)
+    dev = gpu
+    layer = pack.pack_layer(torch.from_numpy(idx_nk).to(dev), torch.from_numpy(lut).to(dev), bits,
+                            torch.from_numpy(outl).to(dev), topX=topX)
+    assert layer["qweight"].is_cuda and layer["full_rows"].shape == (K, topX)
+    assert np.array_equal(layer["qweight"].cpu().numpy(), H.oracle.pack_indices(idx_nk.T, bits))
+    m = QuantLinearLUT.from_operands(layer)
+    x = torch.from_numpy(rng.normal(size=(1, 1, K)).astype(np.float32)).to(dev)
+    y = m(x).reshape(-1).double().cpu().numpy()
+    zero = lut[np.arange(N), np.abs(lut).argmin(1)]
+    W = lut[np.arange(N)[:, None], idx_nk].astype(np.float64) + np.where(outl != 0, outl.astype(np.float64) - zero[:, None], 0)
+    ref = W @ x.reshape(-1).double().cpu().numpy()
+    assert H.rel_err(y, ref) < 1e-5
