@@ -92,6 +92,10 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64; it must be the HIP runtime this library binds to
+    # (device pointers and streams come from torch), so it has to be loaded first
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -m squeezellm_amd.build). "

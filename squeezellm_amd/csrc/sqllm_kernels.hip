@@ -333,7 +333,7 @@ template <int BITS, int BT, int WAVES, int ABL, typename XT>
 __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* __restrict__ y,
                                            const float* lut, int K, int N, int b0, int nb, int bid,
                                            int n_col_tiles, int units_total, int units_per_wg, float* lds,
-                                           const Segment* lin) {
+                                           const Segment& sg, const Segment* lin) {
   using F = Fmt<BITS>;
   constexpr uint32_t XB = sizeof(XT);  // bytes per element of vec (4: operator ABI, 2: fused linear)
   constexpr int L = F::kLut;
@@ -444,10 +444,12 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
       for (int i = 0; i < RPW; ++i) ev[i] = src[2 * (st_h * RPW + i) + (lane >> 5)];
     }
   }
-  // fused linear: the first 64 top-X column indices go out first (consumed right after the
-  // staging barrier, while the weight loads behind them are still in flight)
+  // top-X rows folded into the dense tiles (always for the fused linear; for operator launches
+  // when the plan has no top-X workgroups): the first 64 column indices go out first (consumed
+  // right after the staging barrier, while the weight loads behind them are still in flight)
+  const bool fold_topx = sg.full_rows != nullptr && sg.gm.topx_blocks == 0;
   int topx_idx = -1;
-  if (lin && lin->full_rows) topx_idx = lin->full_idx[lane < lin->gm.topX ? lane : lin->gm.topX - 1];
+  if (fold_topx) topx_idx = sg.full_idx[lane < sg.gm.topX ? lane : sg.gm.topX - 1];
   u32x4 w0[NBUF][R];
   float x0[NXR][BT];
   load_chunk(u_wave, w0, x0);
@@ -458,7 +460,7 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   constexpr int kCodebookFloats = 4 * SUBB / 4;  // the four column sub-tables
   if (tid == 0) *reinterpret_cast<unsigned*>(lds + kCodebookFloats + WAVES * BT * kTileN) = 0u;  // epilogue ticket
   float* topx_sum = lds + kCodebookFloats + WAVES * BT * kTileN + 4;  // [BT][64], fused linear only
-  if (lin && tid < BT * kTileN) topx_sum[tid] = 0.f;
+  if (fold_topx && tid < BT * kTileN) topx_sum[tid] = 0.f;
   // ---- stage the codebooks (row-wise, see above) ----
   if constexpr (!(ABL & 4)) {
     if constexpr (BITS == 4) {
@@ -507,15 +509,15 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
     }
   };
 
-  // ---- fused linear: top-X rows whose column lies in this tile are this workgroup's job too --
-  // their dot product over this K slice joins the column's partial sum, so they need no role, no
+  // ---- folded top-X: rows whose column lies in this tile are this workgroup's job too -- their
+  // dot product over this K slice joins the column's partial sum, so they need no role, no
   // atomics and no counting of their own.  Every wave scans the indices itself (no barrier); a
   // match is rare (topX columns out of N), and its loads overlap the first chunk's.
-  if (lin && lin->full_rows) {
-    const int topX = lin->gm.topX;
+  if (fold_topx) {
+    const int topX = sg.gm.topX;
     const int k_beg = u_beg * F::kK, k_end = u_end * F::kK;
     for (int j0 = 0; j0 < topX; j0 += 64) {
-      const int cj = (j0 == 0) ? topx_idx : lin->full_idx[j0 + lane < topX ? j0 + lane : topX - 1];
+      const int cj = (j0 == 0) ? topx_idx : sg.full_idx[j0 + lane < topX ? j0 + lane : topX - 1];
       unsigned long long m = __ballot(j0 + lane < topX && cj >= col0 && cj < col0 + kTileN);
       while (m) {
         const int jl = __builtin_ctzll(m);
@@ -526,7 +528,7 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
         for (int b = 0; b < BT; ++b) {
           float p = 0.f;
           for (int k = k_beg + wave * 64 + lane; k < k_end; k += WAVES * 64)
-            p = __builtin_fmaf(lin->full_rows[(size_t)k * topX + j],
+            p = __builtin_fmaf(sg.full_rows[(size_t)k * topX + j],
                                (float)x[(size_t)(b0 + (b < nb ? b : nb - 1)) * K + k], p);
           p = wave_sum(p);
           if (lane == 0) atomicAdd(topx_sum + b * kTileN + cc, p);
@@ -608,8 +610,8 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) sum += red[(w * BT + b) * kTileN + lane];
         const size_t at = (size_t)(b0 + b) * N + c;
+        if (fold_topx) sum += topx_sum[b * kTileN + lane];
         if (lin) {
-          if (lin->full_rows) sum += topx_sum[b * kTileN + lane];
           const u64 mine = kCountUnit + to_fixed(sum);
           total[b] = atomicAdd(reinterpret_cast<u64*>(y) + at, mine) + mine;
         } else {
@@ -841,12 +843,12 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
   }
   if (d >= 0 && d < gm.dense_blocks) {
     dense_role<BITS, BT, WAVES, ABL, XT>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, b0, nb,
-                                         d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds, LIN ? &sg : nullptr);
+                                         d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds, sg, LIN ? &sg : nullptr);
   } else if (sp >= 0 && sp < gm.csr_blocks) {
     csr_role<T, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds,
                         LIN ? &sg : nullptr);
   } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
-    // (never taken by fused-linear launches: their plan has no top-X workgroups)
+    // (never taken when the plan folds the top-X rows into the dense tiles)
     topx_role<T, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, b0, nb, sp - gm.csr_blocks, lds);
   }
 }
