@@ -14,7 +14,13 @@
 
 using torch::Tensor;
 
+// refk_set_sync(0): leave the launches asynchronous, as the reference does (for timing a whole pass;
+// tests/ref_kernel_bench.py); the default synchronises after every call.
+static int g_sync = 1;
+extern "C" void refk_set_sync(int on) { g_sync = on; }
+
 static int finish() {
+  if (!g_sync) return (int)hipGetLastError();
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) return (int)e;
   return (int)hipGetLastError();
