@@ -47,6 +47,7 @@ namespace sqllm {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // A "unit" is the smallest piece of K that can be decoded on its own: one qweight row (8 k's) for
 // 4-bit, three rows (32 k's, squeezellm/quant.py:185-203) for 3-bit.
@@ -142,26 +143,24 @@ __device__ __forceinline__ float lookup(uint32_t a) {
 // XL = lane (within the 16-lane row) holding x of the stage's first k.
 // ------------------------------------------------------------------------------------------------
 template <int BT, int XL, int ABL>
-__device__ __forceinline__ void fma_stage(const float (&v)[4][8], const float (&xv)[BT], float (&acc)[4][BT]) {
+__device__ __forceinline__ void fma_stage(const float (&v)[4][8], const float (&xv)[BT], f32x2 (&acc)[2][BT]) {
+  // packed fp32 FMAs (v_pk_fma_f32: two columns per instruction, x splat through op_sel): the
+  // kernel is issue-bound and this halves its FMA instructions
 #pragma unroll
   for (int b = 0; b < BT; ++b) {
     const float x0 = row_bcast<XL + 0>(xv[b]), x1 = row_bcast<XL + 1>(xv[b]);
     const float x2 = row_bcast<XL + 2>(xv[b]), x3 = row_bcast<XL + 3>(xv[b]);
     const float x4 = row_bcast<XL + 4>(xv[b]), x5 = row_bcast<XL + 5>(xv[b]);
     const float x6 = row_bcast<XL + 6>(xv[b]), x7 = row_bcast<XL + 7>(xv[b]);
+#define SQLLM_PKFMA(I, X) a = __builtin_elementwise_fma(f32x2{v[2 * jp][I], v[2 * jp + 1][I]}, f32x2{X, X}, a)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float a = acc[j][b];
-      a = __builtin_fmaf(v[j][0], x0, a);
-      a = __builtin_fmaf(v[j][1], x1, a);
-      a = __builtin_fmaf(v[j][2], x2, a);
-      a = __builtin_fmaf(v[j][3], x3, a);
-      a = __builtin_fmaf(v[j][4], x4, a);
-      a = __builtin_fmaf(v[j][5], x5, a);
-      a = __builtin_fmaf(v[j][6], x6, a);
-      a = __builtin_fmaf(v[j][7], x7, a);
-      acc[j][b] = a;
+    for (int jp = 0; jp < 2; ++jp) {
+      f32x2 a = acc[jp][b];
+      SQLLM_PKFMA(0, x0); SQLLM_PKFMA(1, x1); SQLLM_PKFMA(2, x2); SQLLM_PKFMA(3, x3);
+      SQLLM_PKFMA(4, x4); SQLLM_PKFMA(5, x5); SQLLM_PKFMA(6, x6); SQLLM_PKFMA(7, x7);
+      acc[jp][b] = a;
     }
+#undef SQLLM_PKFMA
   }
 }
 
@@ -175,7 +174,7 @@ __device__ __forceinline__ void fma_stage(const float (&v)[4][8], const float (&
 // the ds_read's immediate offset.  XL = lane of the 16-lane row holding x of the row's first k.
 template <int BT, int XL, int ABL>
 __device__ __forceinline__ void step4(const u32x4& slot, const float (&xslot)[BT], bool valid,
-                                      uint32_t lane_off, float (&acc)[4][BT]) {
+                                      uint32_t lane_off, f32x2 (&acc)[2][BT]) {
   uint32_t t[4] = {slot.x, slot.y, slot.z, slot.w};
   float xv[BT];
   SQLLM_PIN4(t[0], t[1], t[2], t[3]);
@@ -184,8 +183,8 @@ __device__ __forceinline__ void step4(const u32x4& slot, const float (&xslot)[BT
   if constexpr (ABL & 2) {
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
-      acc[0][b] += __builtin_bit_cast(float, t[0] ^ t[1]) * xv[b];
-      acc[1][b] += __builtin_bit_cast(float, t[2] ^ t[3]) * xv[b];
+      acc[0][b].x += __builtin_bit_cast(float, t[0] ^ t[1]) * xv[b];
+      acc[1][b].x += __builtin_bit_cast(float, t[2] ^ t[3]) * xv[b];
     }
     return;
   }
@@ -215,7 +214,7 @@ __device__ __forceinline__ void step4(const u32x4& slot, const float (&xslot)[BT
 template <int BT, int Q, int ABL>
 __device__ __forceinline__ void stage3(const uint32_t (&t0)[4], const uint32_t (&t1)[4], const uint32_t (&t2)[4],
                                        const uint32_t (&tb)[4], const float (&xlo)[BT], const float (&xhi)[BT],
-                                       float (&acc)[4][BT]) {
+                                       f32x2 (&acc)[2][BT]) {
   float v[4][8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -235,7 +234,7 @@ __device__ __forceinline__ void stage3(const uint32_t (&t0)[4], const uint32_t (
 
 template <int BT, int ABL>
 __device__ __forceinline__ void step3(const u32x4 (&slot)[3], const float (&xslot0)[BT], const float (&xslot1)[BT],
-                                      bool valid, const uint32_t (&tb)[4], float (&acc)[4][BT]) {
+                                      bool valid, const uint32_t (&tb)[4], f32x2 (&acc)[2][BT]) {
   uint32_t t0[4] = {slot[0].x, slot[0].y, slot[0].z, slot[0].w};
   uint32_t t1[4] = {slot[1].x, slot[1].y, slot[1].z, slot[1].w};
   uint32_t t2[4] = {slot[2].x, slot[2].y, slot[2].z, slot[2].w};
@@ -476,11 +475,11 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
     }
   }
 
-  float acc[4][BT];
+  f32x2 acc[2][BT];  // [column pair][batch row]: columns 2p and 2p+1 of the lane's four
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
-    for (int b = 0; b < BT; ++b) acc[j][b] = 0.f;
+    for (int b = 0; b < BT; ++b) acc[jp][b] = f32x2{0.f, 0.f};
 
   // per-lane LDS byte offset inside an entry row (4-bit) / per-sub-table bases (3-bit)
   const uint32_t lane_off = 4 * (i16 + 16 * (grp & 1));  // 4-bit: dword slot inside a 128-byte half row
@@ -547,19 +546,20 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   }
 
   if constexpr (ABL & 8) {
-    if (acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] == 12345.678f) y[0] = 1.f;  // keep the work alive
+    if (acc[0][0].x + acc[0][0].y + acc[1][0].x + acc[1][0].y == 12345.678f) y[0] = 1.f;  // keep the work alive
     return;
   }
   // ---- fold the 4 lane rows, then the waves through LDS (codebooks are dead now); one atomic
   //      per column.  Batch rows go through in chunks of CB so the buffer stays small. ----
+  float col[4][BT];  // this lane's four columns, summed over the wave's 4 lane rows
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
-      float a = acc[j][b];
+      float a = (j & 1) ? acc[j >> 1][b].y : acc[j >> 1][b].x;
       a += __shfl_xor(a, 16, 64);
       a += __shfl_xor(a, 32, 64);
-      acc[j][b] = a;
+      col[j][b] = a;
     }
   if constexpr (ABL & 32) {
     // variant: no cross-wave combine, every wave adds its own 64 partial sums
@@ -569,7 +569,7 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
         const int c = col0 + 4 * i16 + j;
 #pragma unroll
         for (int b = 0; b < BT; ++b)
-          if (c < N && b < nb) atomicAdd(y + (size_t)(b0 + b) * N + c, acc[j][b]);
+          if (c < N && b < nb) atomicAdd(y + (size_t)(b0 + b) * N + c, col[j][b]);
       }
     }
     return;
@@ -585,7 +585,7 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   if (grp == 0) {
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
-      f32x4 v = {acc[0][b], acc[1][b], acc[2][b], acc[3][b]};
+      f32x4 v = {col[0][b], col[1][b], col[2][b], col[3][b]};
       *reinterpret_cast<f32x4*>(red + (wave * BT + b) * kTileN + 4 * i16) = v;
     }
   }
@@ -809,9 +809,8 @@ __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
 // the fused kernel
 // ------------------------------------------------------------------------------------------------
 template <int BITS, int BT, int WAVES, int ABL, bool LIN>
-// occupancy target: 2 workgroups of 8 waves per CU (<= 128 VGPRs); the 3-bit kernels with a wide
-// batch tile need more registers and settle for one workgroup per CU rather than spill
-__global__ void __launch_bounds__(WAVES * 64, (ABL & 64) ? 8 : (BITS == 3 && BT >= 4) ? 2 : 4)
+// occupancy target: 2 workgroups of 8 waves per CU (<= 128 VGPRs; every instantiation fits)
+__global__ void __launch_bounds__(WAVES * 64, (ABL & 64) ? 8 : 4)
 sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
   constexpr int T = WAVES * 64;
   constexpr int kLds = lds_floats(Fmt<BITS>::kLut, WAVES, BT);
