@@ -19,6 +19,7 @@ std::atomic<int> g_cu_count{0};
 std::atomic<int> g_ablate{0};
 std::atomic<int> g_sparse_last{0};
 std::atomic<int> g_topx_fold{0};
+std::atomic<int> g_ablate_csr{0};
 
 int cu_count() {
   int c = g_cu_count.load(std::memory_order_relaxed);
@@ -101,6 +102,9 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm) {
   gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
   gm->sparse_last = g_sparse_last.load(std::memory_order_relaxed);
   if (gm->sparse_last) gm->dense_block0 = gm->csr_blocks + gm->topx_blocks;  // grid = dense + sparse
+#ifdef SQLLM_ABLATION_BUILD
+  gm->sparse_last |= g_ablate_csr.load(std::memory_order_relaxed) << 1;  // CSR-role ablation bits ride along
+#endif
 }
 
 }  // namespace
@@ -135,6 +139,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "cu_count")) { g_cu_count.store(value); return SQLLM_OK; }  // for GPU-less planning tests
 #ifdef SQLLM_ABLATION_BUILD
   if (!strcmp(name, "ablate")) { g_ablate.store(value); return SQLLM_OK; }
+  if (!strcmp(name, "ablate_csr")) { g_ablate_csr.store(value); return SQLLM_OK; }
 #endif
   return SQLLM_E_OPTION;
 }
@@ -224,7 +229,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       sg.bias = lin[i].bias;
       // the top-X rows are always handled inside the dense workgroups: no top-X role in the grid
       sg.gm.topx_blocks = 0;
-      if (!sg.gm.sparse_last) sg.gm.dense_block0 = (sg.gm.csr_blocks + 7) / 8 * 8;
+      if (!(sg.gm.sparse_last & 1)) sg.gm.dense_block0 = (sg.gm.csr_blocks + 7) / 8 * 8;
       else sg.gm.dense_block0 = sg.gm.csr_blocks;
       // the 55-bit sum field holds at most kMaxContrib clamped contributions per column: the K
       // slices and one per CSR chunk a row can be spread over

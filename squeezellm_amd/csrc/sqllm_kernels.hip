@@ -644,17 +644,21 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
 //   then, LDS only: each non-zero finds its row by binary search in the staged pointers, products
 //   are summed per row in LDS, and each touched row leaves as one atomic.
 // ------------------------------------------------------------------------------------------------
-template <int T, typename XT, typename AT>
+template <int T, int BT, typename XT, typename AT>
 __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
                                          const int* __restrict__ rows, const int* __restrict__ cols,
                                          const float* __restrict__ vals, int nnz, int K, int N, int b0,
-                                         int nb, int chunk, float* lds, const Segment* lin) {
+                                         int nb, int chunk, float* lds, const Segment* lin, int lin_or_abl_bits = 0) {
   constexpr bool LIN = sizeof(AT) == 8;
   const int tid = threadIdx.x;
   const int e0 = chunk * kCsrChunk;
   int e1 = e0 + kCsrChunk;
   if (e1 > nnz) e1 = nnz;
   if (e0 >= e1) return;
+#ifdef SQLLM_ABLATION_BUILD
+  const int cabl = lin_or_abl_bits;  // 1 = skip the role, 2 = skip the flush, 4 = skip the accumulation
+  if (cabl & 1) return;
+#endif
 
   // ---- round 1 ----
   constexpr int EPT = kCsrChunk / T;  // non-zeros per thread: e0 + tid + T * i (coalesced)
@@ -709,57 +713,109 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
     }
     lr[i] = (e < e1) ? lo : -1;
   }
+  // segment structure of each 64-lane run of non-zeros (fixed for all batch rows): bit d = the lane
+  // 2^d below belongs to the same row (take its partial sum in scan step d), bit 6 = last lane of
+  // its row segment
+  unsigned seg[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int lane = tid & 63;
+    unsigned m = 0;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      const int below = __shfl_up(lr[i], 1 << d, 64);
+      if (lane >= (1 << d) && below == lr[i]) m |= 1u << d;
+    }
+    const int above = __shfl_down(lr[i], 1, 64);
+    if (lane == 63 || above != lr[i]) m |= 64u;
+    seg[i] = m;
+  }
 
-  for (int b = 0; b < nb; ++b) {
-    AT* yb = y + (size_t)(b0 + b) * N + c_lo;
+  // Batch rows go through in groups of `g`: as many as have room for their n row sums each in the
+  // LDS accumulator (all of them for typical chunks, which span 50-100 rows), so a batched op
+  // pays the zero / accumulate / flush round and its three barriers once, not once per row, and
+  // the x gathers of all rows are in flight together.
+  int g = 1;
+  if (in_lds) {
+    g = kCsrSpanMax / n;
+    if (g > nb) g = nb;
+    if (g < 1) g = 1;
+  }
+  const int nm1 = n - 1 > 0 ? n - 1 : 1;
+  for (int bs = 0; bs < nb; bs += g) {
+    const int gb = nb - bs < g ? nb - bs : g;
     if (in_lds) {
-      for (int i = tid; i < n; i += T) sacc[i] = 0.f;
+      for (int i = tid; i < n * gb; i += T) sacc[i] = 0.f;
       __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-      const float xv = (b == 0) ? xg[i] : (float)x[(size_t)(b0 + b) * K + col[i]];
-      const float p = val[i] * xv;
+      float xv[BT];
+#pragma unroll
+      for (int bb = 0; bb < BT; ++bb) {  // unconditional loads (rows past the group re-read its last row)
+        const int bi = bs + (bb < gb ? bb : gb - 1);
+        xv[bb] = (float)x[(size_t)(b0 + bi) * K + col[i]];
+      }
+      if (bs == 0) xv[0] = xg[i];
+      // a wave holds 64 consecutive non-zeros, i.e. a few whole or partial rows: segmented
+      // inclusive scan by row across the lanes, then ONE add per row segment (from its last lane)
+      // instead of 64 adds that collide on 2-3 addresses -- LDS float atomics to one address are
+      // executed one lane at a time (measured: 17 of 49 us of a batch-8 13B hybrid launch).
       const int r = lr[i];
-      // a wave holds 64 consecutive non-zeros: inside a long row they all share the row, so
-      // reduce in registers and issue one atomic instead of 64 colliding ones
-      const int r_first = __builtin_amdgcn_readfirstlane(r);
-      if (__all(r == r_first)) {
-        const float sum = wave_sum(p);
-        if ((tid & 63) == 0 && r_first >= 0) {
-          if (in_lds) atomicAdd(sacc + r_first, sum); else acc_add(yb + r_first, sum);
+      const unsigned sm = seg[i];
+#ifdef SQLLM_ABLATION_BUILD
+      if (cabl & 4) continue;
+#endif
+#pragma unroll
+      for (int bb = 0; bb < BT; ++bb) {
+        if (bb < gb) {
+          float p = val[i] * xv[bb];
+#pragma unroll
+          for (int d = 0; d < 6; ++d) {
+            const float up = __shfl_up(p, 1 << d, 64);
+            if (sm & (1u << d)) p += up;
+          }
+          if ((sm & 64u) && r >= 0) {
+            if (in_lds) atomicAdd(sacc + bb * n + r, p);
+            else acc_add(y + (size_t)(b0 + bs + bb) * N + c_lo + r, p);
+          }
         }
-      } else if (r >= 0) {
-        if (in_lds) atomicAdd(sacc + r, p); else acc_add(yb + r, p);
       }
     }
     if (in_lds) {
       __syncthreads();
-      for (int i = tid; i < n - 1; i += T) {
-        const float sum = sacc[i];
+#ifdef SQLLM_ABLATION_BUILD
+      if (cabl & 2) continue;
+#endif
+      for (int idx = tid; idx < nm1 * gb && n > 1; idx += T) {
+        const int bb = idx / nm1;
+        const int i = idx - bb * nm1;
+        const float sum = sacc[bb * n + i];
+        const size_t at = (size_t)(b0 + bs + bb) * N + c_lo + i;
         if constexpr (LIN) {
           // one COUNTED contribution per row this chunk holds a part of, whatever its value
           const int r0 = srows[i], r1 = srows[i + 1];
           if ((r0 > e0 ? r0 : e0) < (r1 < e1 ? r1 : e1)) {
             const u64 mine = kCountUnit + to_fixed(sum);
             const unsigned target = (unsigned)lin->gm.k_slices + (unsigned)csr_chunks_of_row(r0, r1);
-            column_done(*lin, yb + i, atomicAdd(yb + i, mine) + mine, target, (size_t)(b0 + b) * N + c_lo + i, c_lo + i);
+            column_done(*lin, y + at, atomicAdd(y + at, mine) + mine, target, at, c_lo + i);
           }
         } else {
-          if (sum != 0.f) acc_add(yb + i, sum);
+          if (sum != 0.f) acc_add(y + at, sum);
         }
       }
       __syncthreads();
     } else if constexpr (LIN) {
-      // the values went in uncounted, one add per non-zero; once they are acknowledged, count
-      // this chunk on every row it holds a part of
+      // (g == 1 here) the values went in uncounted, one add per non-zero; once they are
+      // acknowledged, count this chunk on every row it holds a part of
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       for (int i = tid; i < n - 1; i += T) {
         const int r0 = rows[c_lo + i], r1 = rows[c_lo + i + 1];
         if ((r0 > e0 ? r0 : e0) < (r1 < e1 ? r1 : e1)) {
+          const size_t at = (size_t)(b0 + bs) * N + c_lo + i;
           const unsigned target = (unsigned)lin->gm.k_slices + (unsigned)csr_chunks_of_row(r0, r1);
-          column_done(*lin, yb + i, atomicAdd(yb + i, kCountUnit) + kCountUnit, target, (size_t)(b0 + b) * N + c_lo + i, c_lo + i);
+          column_done(*lin, y + at, atomicAdd(y + at, kCountUnit) + kCountUnit, target, at, c_lo + i);
         }
       }
     }
@@ -833,7 +889,7 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
 
   // role by block id within the segment: [sparse | pad | dense] or, with sparse_last, [dense | sparse]
   int d, sp;
-  if (gm.sparse_last) {
+  if (gm.sparse_last & 1) {
     d = bid;
     sp = bid - gm.dense_blocks;
   } else {
@@ -844,8 +900,8 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
     dense_role<BITS, BT, WAVES, ABL, XT>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, b0, nb,
                                          d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds, sg, LIN ? &sg : nullptr);
   } else if (sp >= 0 && sp < gm.csr_blocks) {
-    csr_role<T, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds,
-                        LIN ? &sg : nullptr);
+    csr_role<T, BT, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds,
+                        LIN ? &sg : nullptr, gm.sparse_last >> 1);
   } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
     // (never taken when the plan folds the top-X rows into the dense tiles)
     topx_role<T, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, b0, nb, sp - gm.csr_blocks, lds);

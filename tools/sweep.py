@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--total-mb", type=float, default=700.0, help="distinct weight bytes to rotate over")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--sparse-last", type=int, default=0)
+    ap.add_argument("--ablate-csr", type=int, default=0, help="CSR-role ablation bits (ablation build): 1 skip role, 2 skip flush, 4 skip accumulation")
     ap.add_argument("--group", type=int, default=1, help="ops per launch (sharing one input vector)")
     args = ap.parse_args()
     import numpy as np
@@ -36,6 +37,8 @@ def main():
 
     dev = torch.device("cuda:0")
     _lib.set_option("sparse_last", args.sparse_last)
+    if args.ablate_csr:
+        _lib.set_option("ablate_csr", args.ablate_csr)
     rows = []
     for shp in args.shapes.split(","):
         K, N = map(int, shp.split("x"))
