@@ -244,8 +244,6 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     3 x CU count above)
  *   "groups_per_wave" force the K units each wave walks (default 0 = derived from target_wgs)
  *   "sparse_last"     1 = CSR / top-X workgroups after the dense ones in the grid (default 0)
- *   "topx_fold"       1 = operator launches fold the top-X rows into the dense workgroups instead
- *                     of giving them workgroups of their own (default 0; fused linears always fold)
  *   "cu_count"        override the CU count used for planning (GPU-less tests)
  * Returns SQLLM_E_OPTION for an unknown name. */
 int sqllm_set_option(const char* name, int value);

@@ -46,6 +46,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
     extra = ["-DSQLLM_ABLATION_BUILD"] if os.environ.get("SQLLM_ABLATION") == "1" else []
+    if os.environ.get("SQLLM_SCHED_PATTERN"):  # measurement builds: fixed decode-stage schedules
+        extra.append("-DSQLLM_SCHED_PATTERN=" + str(int(os.environ["SQLLM_SCHED_PATTERN"])))
     cmd = [hipcc(), f"--offload-arch={ARCH}", *FLAGS, *extra, "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH + ".tmp"]
     if verbose:

@@ -18,7 +18,6 @@ std::atomic<int> g_groups_per_wave{0};
 std::atomic<int> g_cu_count{0};
 std::atomic<int> g_ablate{0};
 std::atomic<int> g_sparse_last{0};
-std::atomic<int> g_topx_fold{0};
 std::atomic<int> g_ablate_csr{0};
 
 int cu_count() {
@@ -91,13 +90,9 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm) {
   gm->nnz = (op->rows && op->nnz > 0) ? op->nnz : 0;
   gm->csr_blocks = (gm->nnz + sqllm::kCsrChunk - 1) / sqllm::kCsrChunk;
   gm->topX = (op->full_rows && op->topX > 0) ? op->topX : 0;
-  // top-X rows: a role of their own (one workgroup per kTopxRows k's; default for operator
-  // launches -- measured 6 % faster on 7B w3 s45 than folding, whose matched workgroups become
-  // the tail of the launch), or folded into the dense tiles that own their columns ("topx_fold";
-  // always for the fused linear, where it spares the completion counting a second kind of
-  // contributor)
-  gm->topx_blocks = (gm->topX && !g_topx_fold.load(std::memory_order_relaxed))
-                        ? (op->K + sqllm::kTopxRows - 1) / sqllm::kTopxRows : 0;
+  // top-X rows: a role of their own, one workgroup per kTopxRows k's (the fused linear folds them
+  // into the dense tiles instead and drops these workgroups from its plan)
+  gm->topx_blocks = gm->topX ? (op->K + sqllm::kTopxRows - 1) / sqllm::kTopxRows : 0;
   // dense blocks start at a multiple of 8 so that (dense id % 8) is the XCD of the workgroup
   gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
   gm->sparse_last = g_sparse_last.load(std::memory_order_relaxed);
@@ -135,7 +130,6 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "target_wgs")) { g_target_wgs.store(value); return SQLLM_OK; }
   if (!strcmp(name, "groups_per_wave")) { g_groups_per_wave.store(value); return SQLLM_OK; }
   if (!strcmp(name, "sparse_last")) { g_sparse_last.store(value ? 1 : 0); return SQLLM_OK; }
-  if (!strcmp(name, "topx_fold")) { g_topx_fold.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { g_cu_count.store(value); return SQLLM_OK; }  // for GPU-less planning tests
 #ifdef SQLLM_ABLATION_BUILD
   if (!strcmp(name, "ablate")) { g_ablate.store(value); return SQLLM_OK; }
@@ -149,7 +143,6 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "target_wgs")) { *value = g_target_wgs.load(); return SQLLM_OK; }
   if (!strcmp(name, "groups_per_wave")) { *value = g_groups_per_wave.load(); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { *value = g_cu_count.load(); return SQLLM_OK; }
-  if (!strcmp(name, "topx_fold")) { *value = g_topx_fold.load(); return SQLLM_OK; }
   return SQLLM_E_OPTION;
 }
 

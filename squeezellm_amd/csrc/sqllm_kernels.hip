@@ -41,7 +41,13 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "sqllm_kernels.h"
+
+#ifndef SQLLM_SCHED_PATTERN
+#define SQLLM_SCHED_PATTERN 0
+#endif
 
 namespace sqllm {
 
@@ -208,6 +214,29 @@ __device__ __forceinline__ void step4(const u32x4& slot, const float (&xslot)[BT
     v[j][7] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0700u) + off);
   }
   fma_stage<BT, XL, ABL>(v, xv, acc);
+#if SQLLM_SCHED_PATTERN == 1
+  // fixed stage schedule: per column 3 split ops, then address / lookup pairs; the FMAs follow
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+  }
+#elif SQLLM_SCHED_PATTERN == 2
+  // all addresses of a column, then its 8 lookups
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+  }
+#elif SQLLM_SCHED_PATTERN == 3
+  // every address first, then the 32 lookups back to back
+  __builtin_amdgcn_sched_group_barrier(0x002, 44, 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, 32, 0);
+#endif
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -304,9 +333,18 @@ __device__ __forceinline__ void column_done(const Segment& sg, u64* word, u64 to
   atomicExch(word, 0ull);  // result unused: a plain atomic store
 }
 
-// accumulate one UNCOUNTED value: fp32 atomic (operator launches) or fixed-point add (fused linear)
-__device__ __forceinline__ void acc_add(float* p, float v) { atomicAdd(p, v); }
-__device__ __forceinline__ void acc_add(u64* p, float v) { atomicAdd(p, to_fixed(v)); }
+// accumulate one UNCOUNTED value: fp32 atomic (operator launches) or fixed-point add (fused linear).
+// The pointer is cast to the global address space on purpose: through a generic pointer these
+// become FLAT atomics, and a flat operation anywhere upstream in the kernel's control-flow graph
+// makes the compiler treat vmcnt as out of order -- every later wait for a load turns into
+// vmcnt(0), including the codebook staging wait of the dense role (+0.3-0.6 us per launch).
+#define SQLLM_GLOBAL(T, p) reinterpret_cast<__attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p))
+__device__ __forceinline__ void acc_add(float* p, float v) {
+  __hip_atomic_fetch_add(SQLLM_GLOBAL(float, p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void acc_add(u64* p, float v) {
+  __hip_atomic_fetch_add(SQLLM_GLOBAL(u64, p), to_fixed(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ------------------------------------------------------------------------------------------------
 // dense role
@@ -443,12 +481,26 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
       for (int i = 0; i < RPW; ++i) ev[i] = src[2 * (st_h * RPW + i) + (lane >> 5)];
     }
   }
-  // top-X rows folded into the dense tiles (always for the fused linear; for operator launches
-  // when the plan has no top-X workgroups): the first 64 column indices go out first (consumed
-  // right after the staging barrier, while the weight loads behind them are still in flight)
-  const bool fold_topx = sg.full_rows != nullptr && sg.gm.topx_blocks == 0;
+  // Fused linear: the top-X rows are folded into the dense tiles.  The first 64 column indices go
+  // out first (consumed right after the staging barrier, while the weight loads behind them are
+  // still in flight).  The load is UNCONDITIONAL -- without top-X rows it reads the codebook
+  // pointer instead -- because a load under a branch makes the compiler wait for every
+  // outstanding load at the join (measured: vmcnt(0) instead of vmcnt(6) before the codebook
+  // staging, +0.3-0.6 us on every launch).  Operator launches keep the separate top-X role:
+  // folding measured 6 % slower there (the matched workgroups become the tail of the launch).
+  // Branches first: between the loads below and the codebook staging there must be NO control
+  // flow, or the staging waits for every outstanding load (vmcnt(0)) instead of its own.
+  constexpr int kCodebookFloats = 4 * SUBB / 4;  // the four column sub-tables
+  float* topx_sum = lds + kCodebookFloats + WAVES * BT * kTileN + 4;  // [BT][64], fused linear only
+  // epilogue ticket (the dword after the slabs) and, 4 dwords on, the BT * 64 top-X sums
+  for (int i = tid; i < 4 + BT * kTileN; i += WAVES * 64) lds[kCodebookFloats + WAVES * BT * kTileN + i] = 0.f;
+  constexpr bool FOLD = !std::is_same<XT, float>::value;  // == fused-linear instantiation
+  const bool fold_topx = FOLD && sg.full_rows != nullptr;
   int topx_idx = -1;
-  if (fold_topx) topx_idx = sg.full_idx[lane < sg.gm.topX ? lane : sg.gm.topX - 1];
+  if constexpr (FOLD) {
+    const int* fi = fold_topx ? sg.full_idx : reinterpret_cast<const int*>(lut);
+    topx_idx = fi[fold_topx ? (lane < sg.gm.topX ? lane : sg.gm.topX - 1) : 0];
+  }
   u32x4 w0[NBUF][R];
   float x0[NXR][BT];
   load_chunk(u_wave, w0, x0);
@@ -456,10 +508,6 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 
-  constexpr int kCodebookFloats = 4 * SUBB / 4;  // the four column sub-tables
-  if (tid == 0) *reinterpret_cast<unsigned*>(lds + kCodebookFloats + WAVES * BT * kTileN) = 0u;  // epilogue ticket
-  float* topx_sum = lds + kCodebookFloats + WAVES * BT * kTileN + 4;  // [BT][64], fused linear only
-  if (fold_topx && tid < BT * kTileN) topx_sum[tid] = 0.f;
   // ---- stage the codebooks (row-wise, see above) ----
   if constexpr (!(ABL & 4)) {
     if constexpr (BITS == 4) {
@@ -686,11 +734,22 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
   // ---- round 2 ----
   int* srows = reinterpret_cast<int*>(lds);  // [kCsrSpanMax]
   float* sacc = lds + kCsrSpanMax;           // [kCsrSpanMax]
-  if (in_lds)
-    for (int i = tid; i < n; i += T) srows[i] = rows[c_lo + i];
+  // the gather goes out first: the staging loop below waits for its own loads before it stores
   float xg[EPT];
 #pragma unroll
   for (int i = 0; i < EPT; ++i) xg[i] = (float)x[(size_t)b0 * K + col[i]];  // first batch row's gather
+  // Batch rows go through in groups of `g`: as many as have room for their n row sums each in the
+  // LDS accumulator (all of them for typical chunks, which span 50-100 rows), so a batched op
+  // pays the zero / accumulate / flush round and its barriers once, not once per row, and the x
+  // gathers of all rows are in flight together.
+  int g = 1;
+  if (in_lds) {
+    g = kCsrSpanMax / n;
+    if (g > nb) g = nb;
+    if (g < 1) g = 1;
+    for (int i = tid; i < n; i += T) srows[i] = rows[c_lo + i];
+    for (int i = tid; i < n * g; i += T) sacc[i] = 0.f;  // first group's sums (no barrier of its own)
+  }
   __syncthreads();
 
   // local row of each non-zero: largest i with rows[c_lo + i] <= e
@@ -731,20 +790,10 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
     seg[i] = m;
   }
 
-  // Batch rows go through in groups of `g`: as many as have room for their n row sums each in the
-  // LDS accumulator (all of them for typical chunks, which span 50-100 rows), so a batched op
-  // pays the zero / accumulate / flush round and its three barriers once, not once per row, and
-  // the x gathers of all rows are in flight together.
-  int g = 1;
-  if (in_lds) {
-    g = kCsrSpanMax / n;
-    if (g > nb) g = nb;
-    if (g < 1) g = 1;
-  }
   const int nm1 = n - 1 > 0 ? n - 1 : 1;
   for (int bs = 0; bs < nb; bs += g) {
     const int gb = nb - bs < g ? nb - bs : g;
-    if (in_lds) {
+    if (in_lds && bs > 0) {
       for (int i = tid; i < n * gb; i += T) sacc[i] = 0.f;
       __syncthreads();
     }

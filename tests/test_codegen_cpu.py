@@ -1,0 +1,65 @@
+"""Guards on the generated gfx950 code of the fused kernel (hipcc cross-compiles without a GPU).
+
+Each of these was a measured regression at some point of the build:
+  * a FLAT memory instruction anywhere in the kernel makes the compiler treat vmcnt as out of order,
+    and every later wait for a load degrades to vmcnt(0) -- including the dense role's codebook
+    staging wait, which must leave the already issued weight loads in flight (+0.3-0.6 us/launch);
+  * register spills / scratch in the decode loop;
+  * more than 128 VGPRs (two 8-wave workgroups per CU no longer fit).
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from squeezellm_amd import build as B
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("asm") / "k.s"
+    cmd = [hipcc, f"--offload-arch={B.ARCH}", *[f for f in B.FLAGS if f != "-fPIC"], "-S", "--cuda-device-only",
+           f"-I{B.INCLUDE}", f"-I{B.CSRC}", os.path.join(B.CSRC, "sqllm_kernels.hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return out.read_text()
+
+
+def _kernels(asm):
+    out = {}
+    for m in re.finditer(r"^(_ZN5sqllm18sqllm_fused_matvec\w+):.*?^\.Lfunc_end", asm, re.S | re.M):
+        out[m.group(1)] = m.group(0).split("\n")
+    return out
+
+
+def test_all_instantiations_present(asm):
+    ks = _kernels(asm)
+    assert len(ks) == 16  # {3,4} bits x batch tile {1,2,4,8} x {operator, fused linear}
+
+
+def test_no_flat_memory_instructions(asm):
+    for name, body in _kernels(asm).items():
+        flat = [l.strip() for l in body if re.match(r"\s+flat_", l)]
+        assert not flat, f"{name}: {flat[:3]}"
+
+
+def test_codebook_staging_wait_leaves_the_weight_loads_in_flight(asm):
+    for name, body in _kernels(asm).items():
+        i0 = next(i for i, l in enumerate(body) if "global_load_dwordx4" in l and " nt" in l)  # dense role's first weight load
+        i1 = next(i for i in range(i0, len(body)) if "s_barrier" in body[i])                 # the staging barrier
+        waits = [int(m.group(1)) for l in body[i0:i1] for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", l)] if m]
+        assert waits and min(waits) >= 3, f"{name}: waits {waits} between the first weight load and the staging barrier"
+
+
+def test_no_spills_and_two_workgroups_per_cu(asm):
+    meta = re.findall(r"\.name:\s+(_ZN5sqllm18sqllm_fused_matvec\w+).*?\.private_segment_fixed_size:\s+(\d+).*?"
+                      r"\.sgpr_spill_count:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", asm, re.S)
+    assert len(meta) == 16
+    for name, scratch, sspill, vgpr, vspill in meta:
+        # (a few SGPRs parked in VGPR lanes are tolerated: no memory traffic; scratch is not)
+        assert int(scratch) == 0 and int(vspill) == 0 and int(sspill) <= 16, (name, scratch, sspill, vspill)
+        assert int(vgpr) <= 128, (name, vgpr)

@@ -203,31 +203,3 @@ def test_linear_counts_every_kind_of_sparse_contribution(gpu, bits, rows):
     for _ in range(2):
         _check_fp16(mod(x).reshape(rows, N).cpu().numpy(), exact)
     assert int(next(iter(mod._ws.values())).count_nonzero()) == 0
-
-
-@pytest.mark.parametrize("bits", [3, 4])
-@pytest.mark.parametrize("batched", [False, True])
-def test_operator_launch_with_folded_topx_option(gpu, bits, batched):
-    """The "topx_fold" planning option (top-X rows computed by the dense workgroups that own their
-    columns; off by default for operator launches) must not change the operator's result."""
-    import torch
-
-    import quant_cuda as qc
-    from squeezellm_amd import _lib, synth
-
-    K, N, B = 1024, 456, 3
-    lay = synth.make_layer(K, N, bits, sparse_frac=0.01, topX=5, heavy_rows=2, device=gpu, seed=3 + bits)
-    lay["full_row_indices"][1] = lay["full_row_indices"][0]
-    npl = _npl(lay)
-    x = torch.randn((B, K) if batched else (K,), device=gpu)
-    mul0 = torch.randn((B, N) if batched else (N,), device=gpu)
-    ref = H.oracle_ref(npl, x.cpu().numpy(), mul0.cpu().numpy(), "hybrid")
-    try:
-        for fold in (1, 0):
-            _lib.set_option("topx_fold", fold)
-            assert _lib.get_option("topx_fold") == fold
-            y = mul0.clone()
-            H.call_op(qc, lay, x, y, "hybrid", batched)
-            assert H.rel_err(y.cpu().numpy(), ref) < 2e-5
-    finally:
-        _lib.set_option("topx_fold", 0)
