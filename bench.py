@@ -115,6 +115,37 @@ def cpu_baseline(layers, model_layers: int, budget_s: float = 12.0):
                        f"C port oracle/sqllm_oracle.c with OpenMP, best layer {best * 1e3:.1f} ms, scaled x{model_layers}")
 
 
+def pmc_traffic_per_launch(config_name: str, fused: bool):
+    """Mean HBM bytes per launch of this config from the committed rocprofv3 PMC summaries
+    (profiles/r01_pmc_fetch[_w3].summary.txt + r01_pmc_write.summary.txt, collected by
+    tools/collect_profiles.sh with the same launch grouping): FETCH_SIZE [KiB] x 2 (gfx950 tallies the
+    128-B requests of wide coalesced reads at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE [KiB]."""
+    import re
+
+    names = {"7b-w4-s0": ("r01_pmc_fetch.summary.txt", "r01_pmc_write.summary.txt"),
+             "7b-w3-s45": ("r01_pmc_fetch_w3.summary.txt", None)}
+    if config_name not in names or not fused:
+        return None
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+
+    def mean_kib(fname, counter):
+        try:
+            txt = open(os.path.join(prof, fname)).read()
+        except OSError:
+            return None
+        rows = re.findall(rf"grid=\d+\s+{counter}\s+n=(\d+)\s+mean=\s*([\d,\.]+)", txt)
+        if not rows:
+            return None
+        n = sum(int(a) for a, _ in rows)
+        return sum(int(a) * float(b.replace(",", "")) for a, b in rows) / n
+
+    fetch = mean_kib(names[config_name][0], "FETCH_SIZE")
+    if fetch is None:
+        return None
+    write = mean_kib(names[config_name][1], "WRITE_SIZE") if names[config_name][1] else 0.0
+    return int((2.0 * fetch + (write or 0.0)) * 1024)
+
+
 def main():
     args = parse_args()
     import torch
@@ -262,7 +293,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,  # PMC FETCH_SIZE/WRITE_SIZE come from separate rocprofv3 --pmc runs (profiles/)
+                # HBM bytes per launch from the PMC counters: they cannot be read live (rocprofv3 --pmc
+                # passes, one counter group each), so this is the committed summary of those passes
+                # for this config, gfx950 correction applied (FETCH_SIZE x 2); null if none is committed
+                "traffic": pmc_traffic_per_launch(args.config, not args.no_fuse),
                 "kernel": f"sqllm_fused_matvec<{cfg['bits']},1>",
                 "avg_kernel_us": round(avg_us, 3),
                 "launches_per_step": n_launch,

@@ -216,3 +216,22 @@ def test_gpu_packed_layer_runs_through_the_module(gpu, bits):
     W = lut[np.arange(N)[:, None], idx_nk].astype(np.float64) + np.where(outl != 0, outl.astype(np.float64) - zero[:, None], 0)
     ref = W @ x.reshape(-1).double().cpu().numpy()
     assert H.rel_err(y, ref) < 1e-5
+
+
+def test_c_abi_demo_builds_and_runs_without_python_in_the_loop(gpu, tmp_path):
+    """examples/c_abi_demo.c: plain C against include/sqllm_hip.h + libsqllm_hip.so (operator and
+    fused linear), compiled here with gcc and run as its own process."""
+    import shutil
+    import subprocess
+
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if not shutil.which("gcc") or not os.path.exists(os.path.join(rocm, "include", "hip", "hip_runtime_api.h")):
+        pytest.skip("gcc / ROCm headers not available on this box")
+    libdir = os.path.join(H.ROOT, "squeezellm_amd")
+    exe = str(tmp_path / "c_abi_demo")
+    subprocess.run(["gcc", "-std=c99", "-O2", "-D__HIP_PLATFORM_AMD__", f"-I{rocm}/include", f"-I{os.path.join(H.ROOT, 'include')}",
+                    os.path.join(H.ROOT, "examples", "c_abi_demo.c"), f"-L{libdir}", "-lsqllm_hip", f"-L{rocm}/lib", "-lamdhip64",
+                    f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{rocm}/lib", "-lm", "-o", exe], check=True, capture_output=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "ok (ABI version 1)" in res.stdout and "more than one fp16 ulp: 0 of" in res.stdout
