@@ -19,6 +19,7 @@ std::atomic<int> g_cu_count{0};
 std::atomic<int> g_ablate{0};
 std::atomic<int> g_sparse_last{0};
 std::atomic<int> g_ablate_csr{0};
+std::atomic<void*> g_timeline{nullptr};  // measurement build: per-workgroup timestamp buffer
 
 int cu_count() {
   int c = g_cu_count.load(std::memory_order_relaxed);
@@ -125,6 +126,11 @@ const char* sqllm_error_string(int code) {
   return "unknown sqllm error";
 }
 
+#ifdef SQLLM_ABLATION_BUILD
+// measurement build only (not in the header): device buffer of 8 x u64 per workgroup of the next launches
+void sqllm_debug_set_timeline(void* buf) { g_timeline.store(buf); }
+#endif
+
 int sqllm_set_option(const char* name, int value) {
   if (!name || value < 0) return SQLLM_E_OPTION;
   if (!strcmp(name, "target_wgs")) { g_target_wgs.store(value); return SQLLM_OK; }
@@ -214,6 +220,9 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     sg.full_idx = op->full_row_indices;
     sg.bias = nullptr;
     sg.out16 = nullptr;
+#ifdef SQLLM_ABLATION_BUILD
+    if (!lin) sg.bias = static_cast<const float*>(g_timeline.load(std::memory_order_relaxed));
+#endif
     make_plan(op, &sg.gm);
     if (lin) {
       // accumulate into the workspace plane; op->mul is the fp16 result

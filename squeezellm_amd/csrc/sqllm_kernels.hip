@@ -488,6 +488,14 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   // outstanding load at the join (measured: vmcnt(0) instead of vmcnt(6) before the codebook
   // staging, +0.3-0.6 us on every launch).  Operator launches keep the separate top-X role:
   // folding measured 6 % slower there (the matched workgroups become the tail of the launch).
+#ifdef SQLLM_ABLATION_BUILD
+  // timeline probe (measurement build): sg.bias, unused by operator launches, carries a buffer of
+  // 8 x u64 per workgroup; wave 0 stamps entry / barrier passed / decode done, the combining wave
+  // stamps the end.  s_memrealtime = 100 MHz constant clock, comparable across CUs.
+  unsigned long long* tl = (!lin && sg.bias) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(sg.bias)) +
+                                                   8ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y) : nullptr;
+  if (tl && tid == 0) tl[0] = __builtin_amdgcn_s_memrealtime();
+#endif
   // Branches first: between the loads below and the codebook staging there must be NO control
   // flow, or the staging waits for every outstanding load (vmcnt(0)) instead of its own.
   constexpr int kCodebookFloats = 4 * SUBB / 4;  // the four column sub-tables
@@ -536,6 +544,9 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   for (int j = 0; j < 4; ++j) tb[j] = j * SUBB + 4 * (i16 + 16 * (grp & 1));
 
   __syncthreads();  // codebooks visible
+#ifdef SQLLM_ABLATION_BUILD
+  if (tl && tid == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // u = this wave's (uniform) unit for the chunk's first step: guards are scalar branches; only the
   // per-row validity of a slice's ragged end is per lane (it zeroes x, no divergence)
@@ -593,6 +604,10 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
     decode_chunk(u0, w, xs);
   }
 
+#ifdef SQLLM_ABLATION_BUILD
+  if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
+  if (tl && lane == 0) tl[4 + (wave & 3)] = __builtin_amdgcn_s_memrealtime();  // decode end of waves 0-3
+#endif
   if constexpr (ABL & 8) {
     if (acc[0][0].x + acc[0][0].y + acc[1][0].x + acc[1][0].y == 12345.678f) y[0] = 1.f;  // keep the work alive
     return;
@@ -667,6 +682,9 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
         }
       }
     }
+#ifdef SQLLM_ABLATION_BUILD
+    if (tl && lane == 0) tl[3] = __builtin_amdgcn_s_memrealtime();  // atomics issued by the combining wave
+#endif
     if (lin) {  // all the round trips are in flight before the first result is looked at
 #pragma unroll
       for (int b = 0; b < BT; ++b) {
