@@ -347,6 +347,106 @@ __device__ __forceinline__ void acc_add(u64* p, float v) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Dense epilogue (shared by the dense-role variants): fold the 4 lane rows, then the waves through
+// LDS, one atomic per column.  `slabs` = LDS area [WAVES][BT][64] floats followed by the ticket.
+// ------------------------------------------------------------------------------------------------
+template <int BT, int WAVES, int ABL>
+__device__ __forceinline__ void dense_epilogue(const f32x2 (&acc)[2][BT], float* slabs, const float* topx_sum,
+                                               bool fold_topx, float* __restrict__ y, int N, int col0, int b0,
+                                               int nb, int lane, int wave, const Segment& sg, const Segment* lin
+#ifdef SQLLM_ABLATION_BUILD
+                                               , unsigned long long* tl
+#endif
+) {
+  const int i16 = lane & 15, grp = lane >> 4;
+  if constexpr (ABL & 8) {
+    if (acc[0][0].x + acc[0][0].y + acc[1][0].x + acc[1][0].y == 12345.678f) y[0] = 1.f;  // keep the work alive
+    return;
+  }
+  // ---- fold the 4 lane rows, then the waves through LDS (codebooks are dead now); one atomic
+  //      per column.  Batch rows go through in chunks of CB so the buffer stays small. ----
+  float col[4][BT];  // this lane's four columns, summed over the wave's 4 lane rows
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      float a = (j & 1) ? acc[j >> 1][b].y : acc[j >> 1][b].x;
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      col[j][b] = a;
+    }
+  if constexpr (ABL & 32) {
+    // variant: no cross-wave combine, every wave adds its own 64 partial sums
+    if (grp == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = col0 + 4 * i16 + j;
+#pragma unroll
+        for (int b = 0; b < BT; ++b)
+          if (c < N && b < nb) atomicAdd(y + (size_t)(b0 + b) * N + c, col[j][b]);
+      }
+    }
+    return;
+  }
+  // Barrier-free combine: every wave deposits its 64 x BT partial sums in its own LDS slab (a
+  // region the codebooks never occupy, so nobody has to wait for the other waves' lookups), then
+  // takes a ticket; the wave that draws the last ticket sums the slabs and issues the atomics.
+  // Waves that finish early simply leave.  (LDS operations of a CU execute in issue order and a
+  // wave's own LDS operations stay in program order, so the last ticket implies every slab is
+  // written; the fence pins the compiler.)  The two-barrier version cost 1-2.5 us per launch.
+  float* red = slabs;                                                      // [wave][BT][64]
+  unsigned* ticket = reinterpret_cast<unsigned*>(slabs + WAVES * BT * kTileN);
+  if (grp == 0) {
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      f32x4 v = {col[0][b], col[1][b], col[2][b], col[3][b]};
+      *reinterpret_cast<f32x4*>(red + (wave * BT + b) * kTileN + 4 * i16) = v;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  unsigned t = 0;
+  if (lane == 0) t = atomicAdd(ticket, 1u);
+  t = __builtin_amdgcn_readfirstlane(t);
+  if (t != WAVES - 1) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const int c = col0 + lane;
+  if (c < N) {
+    u64 total[BT];
+    unsigned target = 0;
+    if (lin) {  // contributions this column receives: K slices + the CSR chunks its row is spread over
+      target = (unsigned)lin->gm.k_slices;
+      if (lin->gm.csr_blocks) target += (unsigned)csr_chunks_of_row(lin->rows[c], lin->rows[c + 1]);
+    }
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      if (b < nb) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) sum += red[(w * BT + b) * kTileN + lane];
+        const size_t at = (size_t)(b0 + b) * N + c;
+        if (fold_topx) sum += topx_sum[b * kTileN + lane];
+        if (lin) {
+          const u64 mine = kCountUnit + to_fixed(sum);
+          total[b] = atomicAdd(reinterpret_cast<u64*>(y) + at, mine) + mine;
+        } else {
+          atomicAdd(y + at, sum);
+        }
+      }
+    }
+#ifdef SQLLM_ABLATION_BUILD
+    if (tl && lane == 0) tl[3] = __builtin_amdgcn_s_memrealtime();  // atomics issued by the combining wave
+#endif
+    if (lin) {  // all the round trips are in flight before the first result is looked at
+#pragma unroll
+      for (int b = 0; b < BT; ++b) {
+        const size_t at = (size_t)(b0 + b) * N + c;
+        if (b < nb) column_done(*lin, reinterpret_cast<u64*>(y) + at, total[b], target, at, c);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // dense role
 //
 // Codebook layout in LDS (bytes):  addr(j, idx, slot) = j * SUBB + idx * ESTRIDE + 4 * slot
@@ -373,6 +473,11 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
                                            const Segment& sg, const Segment* lin) {
   using F = Fmt<BITS>;
   constexpr uint32_t XB = sizeof(XT);  // bytes per element of vec (4: operator ABI, 2: fused linear)
+  // Clean slate for the compiler's wait-count model: the other roles sit upstream of this one in
+  // the kernel's (static) control-flow graph, and whatever memory operation they leave "pending"
+  // there (a FLAT access, a load into a register this role reuses) would otherwise be waited for
+  // inside THIS role, conservatively.  Nothing is really outstanding here: the wait is free.
+  __builtin_amdgcn_s_waitcnt(0);
   constexpr int L = F::kLut;
   constexpr int R = F::kRows;
   constexpr int ESTRIDE = (BITS == 4) ? 256 : 128;                 // bytes between consecutive entries
@@ -608,91 +713,11 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
   if (tl && lane == 0) tl[4 + (wave & 3)] = __builtin_amdgcn_s_memrealtime();  // decode end of waves 0-3
 #endif
-  if constexpr (ABL & 8) {
-    if (acc[0][0].x + acc[0][0].y + acc[1][0].x + acc[1][0].y == 12345.678f) y[0] = 1.f;  // keep the work alive
-    return;
-  }
-  // ---- fold the 4 lane rows, then the waves through LDS (codebooks are dead now); one atomic
-  //      per column.  Batch rows go through in chunks of CB so the buffer stays small. ----
-  float col[4][BT];  // this lane's four columns, summed over the wave's 4 lane rows
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int b = 0; b < BT; ++b) {
-      float a = (j & 1) ? acc[j >> 1][b].y : acc[j >> 1][b].x;
-      a += __shfl_xor(a, 16, 64);
-      a += __shfl_xor(a, 32, 64);
-      col[j][b] = a;
-    }
-  if constexpr (ABL & 32) {
-    // variant: no cross-wave combine, every wave adds its own 64 partial sums
-    if (grp == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = col0 + 4 * i16 + j;
-#pragma unroll
-        for (int b = 0; b < BT; ++b)
-          if (c < N && b < nb) atomicAdd(y + (size_t)(b0 + b) * N + c, col[j][b]);
-      }
-    }
-    return;
-  }
-  // Barrier-free combine: every wave deposits its 64 x BT partial sums in its own LDS slab (a
-  // region the codebooks never occupy, so nobody has to wait for the other waves' lookups), then
-  // takes a ticket; the wave that draws the last ticket sums the slabs and issues the atomics.
-  // Waves that finish early simply leave.  (LDS operations of a CU execute in issue order and a
-  // wave's own LDS operations stay in program order, so the last ticket implies every slab is
-  // written; the fence pins the compiler.)  The two-barrier version cost 1-2.5 us per launch.
-  float* red = lds + kCodebookFloats;                                      // [wave][BT][64]
-  unsigned* ticket = reinterpret_cast<unsigned*>(lds + kCodebookFloats + WAVES * BT * kTileN);
-  if (grp == 0) {
-#pragma unroll
-    for (int b = 0; b < BT; ++b) {
-      f32x4 v = {col[0][b], col[1][b], col[2][b], col[3][b]};
-      *reinterpret_cast<f32x4*>(red + (wave * BT + b) * kTileN + 4 * i16) = v;
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  unsigned t = 0;
-  if (lane == 0) t = atomicAdd(ticket, 1u);
-  t = __builtin_amdgcn_readfirstlane(t);
-  if (t != WAVES - 1) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  const int c = col0 + lane;
-  if (c < N) {
-    u64 total[BT];
-    unsigned target = 0;
-    if (lin) {  // contributions this column receives: K slices + the CSR chunks its row is spread over
-      target = (unsigned)lin->gm.k_slices;
-      if (lin->gm.csr_blocks) target += (unsigned)csr_chunks_of_row(lin->rows[c], lin->rows[c + 1]);
-    }
-#pragma unroll
-    for (int b = 0; b < BT; ++b) {
-      if (b < nb) {
-        float sum = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) sum += red[(w * BT + b) * kTileN + lane];
-        const size_t at = (size_t)(b0 + b) * N + c;
-        if (fold_topx) sum += topx_sum[b * kTileN + lane];
-        if (lin) {
-          const u64 mine = kCountUnit + to_fixed(sum);
-          total[b] = atomicAdd(reinterpret_cast<u64*>(y) + at, mine) + mine;
-        } else {
-          atomicAdd(y + at, sum);
-        }
-      }
-    }
+  dense_epilogue<BT, WAVES, ABL>(acc, lds + kCodebookFloats, topx_sum, fold_topx, y, N, col0, b0, nb, lane, wave, sg, lin
 #ifdef SQLLM_ABLATION_BUILD
-    if (tl && lane == 0) tl[3] = __builtin_amdgcn_s_memrealtime();  // atomics issued by the combining wave
+                                 , tl
 #endif
-    if (lin) {  // all the round trips are in flight before the first result is looked at
-#pragma unroll
-      for (int b = 0; b < BT; ++b) {
-        const size_t at = (size_t)(b0 + b) * N + c;
-        if (b < nb) column_done(*lin, reinterpret_cast<u64*>(y) + at, total[b], target, at, c);
-      }
-    }
-  }
+  );
 }
 
 // ------------------------------------------------------------------------------------------------
