@@ -48,6 +48,13 @@
 #ifndef SQLLM_SCHED_PATTERN
 #define SQLLM_SCHED_PATTERN 0
 #endif
+#ifndef SQLLM_PIPE
+#define SQLLM_PIPE 0
+#endif
+#ifndef SQLLM_HALF_STAGES
+#define SQLLM_HALF_STAGES 1  // 0 (measurement builds): whole-stage decode, 32 live lookups
+#endif
+
 
 namespace sqllm {
 
@@ -240,10 +247,173 @@ __device__ __forceinline__ void step4(const u32x4& slot, const float (&xslot)[BT
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int BT, int Q, int ABL>
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined 4-bit chunk decode (SQLLM_PIPE): the lookups of step s+1 are issued in the same
+// scheduling region as the FMAs of step s, so their LDS latency is covered by the wave's own FMAs
+// instead of by other waves (costs a second set of 32 lookup registers).  Steps past the slice's end
+// are not skipped but multiplied by zero (their weights are clamped re-reads): no branches.
+// ------------------------------------------------------------------------------------------------
+template <int ABL>
+__device__ __forceinline__ void lookup4(const u32x4& slot, uint32_t lane_off, f32x2 (&vp)[2][8]) {
+  uint32_t t[4] = {slot.x, slot.y, slot.z, slot.w};
+  SQLLM_PIN4(t[0], t[1], t[2], t[3]);
+  // vp[p][i] = the values of weights k = i of columns 2p (.x) and 2p+1 (.y): the operand pairs of
+  // the packed FMAs, built in place so that no array of scalars has to be re-paired
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t lo = t[j] & 0x0F0F0F0Fu;
+    const uint32_t hi = (t[j] >> 4) & 0x0F0F0F0Fu;
+    const int off = (j >> 1) * 4096 + (j & 1) * 128;
+    float e[8];
+    e[0] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0400u) + off);
+    e[1] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0400u) + off);
+    e[2] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0500u) + off);
+    e[3] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0500u) + off);
+    e[4] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0600u) + off);
+    e[5] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0600u) + off);
+    e[6] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0700u) + off);
+    e[7] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0700u) + off);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (j & 1) vp[j >> 1][i].y = e[i]; else vp[j >> 1][i].x = e[i];
+    }
+  }
+}
+
+template <int BT, int XL, int ABL>
+__device__ __forceinline__ void fma4(const f32x2 (&vp)[2][8], const float (&xslot)[BT], bool valid, f32x2 (&acc)[2][BT]) {
+#pragma unroll
+  for (int b = 0; b < BT; ++b) {
+    const float xv = valid ? xslot[b] : 0.f;
+    const float x0 = row_bcast<XL + 0>(xv), x1 = row_bcast<XL + 1>(xv), x2 = row_bcast<XL + 2>(xv), x3 = row_bcast<XL + 3>(xv);
+    const float x4 = row_bcast<XL + 4>(xv), x5 = row_bcast<XL + 5>(xv), x6 = row_bcast<XL + 6>(xv), x7 = row_bcast<XL + 7>(xv);
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      f32x2 a = acc[jp][b];
+      a = __builtin_elementwise_fma(vp[jp][0], f32x2{x0, x0}, a);
+      a = __builtin_elementwise_fma(vp[jp][1], f32x2{x1, x1}, a);
+      a = __builtin_elementwise_fma(vp[jp][2], f32x2{x2, x2}, a);
+      a = __builtin_elementwise_fma(vp[jp][3], f32x2{x3, x3}, a);
+      a = __builtin_elementwise_fma(vp[jp][4], f32x2{x4, x4}, a);
+      a = __builtin_elementwise_fma(vp[jp][5], f32x2{x5, x5}, a);
+      a = __builtin_elementwise_fma(vp[jp][6], f32x2{x6, x6}, a);
+      a = __builtin_elementwise_fma(vp[jp][7], f32x2{x7, x7}, a);
+      acc[jp][b] = a;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int BT, int NB, int ABL>
+__device__ __forceinline__ void decode4_pipelined(const u32x4 (&w)[NB][1], const float (&xs)[NB / 2][BT], int u,
+                                                  int grp, int u_end, int step, uint32_t lane_off,
+                                                  f32x2 (&acc)[2][BT]) {
+  static_assert(NB == 2 || NB == 4, "chunk of 2 or 4 steps");
+  f32x2 va[2][8], vb[2][8];
+  lookup4<ABL>(w[0][0], lane_off, va);
+  lookup4<ABL>(w[1][0], lane_off, vb);
+  fma4<BT, 0, ABL>(va, xs[0], u + grp < u_end, acc);
+  if constexpr (NB == 4) {
+    lookup4<ABL>(w[2][0], lane_off, va);
+    fma4<BT, 8, ABL>(vb, xs[0], u + step + grp < u_end, acc);
+    lookup4<ABL>(w[3][0], lane_off, vb);
+    fma4<BT, 0, ABL>(va, xs[1], u + 2 * step + grp < u_end, acc);
+    fma4<BT, 8, ABL>(vb, xs[1], u + 3 * step + grp < u_end, acc);
+  } else {
+    fma4<BT, 8, ABL>(vb, xs[0], u + step + grp < u_end, acc);
+  }
+}
+
+// packed FMAs of ONE column pair: vp[i] = the values of weight k = i of the pair's two columns
+template <int BT, int XL>
+__device__ __forceinline__ void fma_pair(const f32x2 (&vp)[8], const float (&xv)[BT], f32x2 (&acc)[BT]) {
+#pragma unroll
+  for (int b = 0; b < BT; ++b) {
+    const float x0 = row_bcast<XL + 0>(xv[b]), x1 = row_bcast<XL + 1>(xv[b]), x2 = row_bcast<XL + 2>(xv[b]), x3 = row_bcast<XL + 3>(xv[b]);
+    const float x4 = row_bcast<XL + 4>(xv[b]), x5 = row_bcast<XL + 5>(xv[b]), x6 = row_bcast<XL + 6>(xv[b]), x7 = row_bcast<XL + 7>(xv[b]);
+    f32x2 a = acc[b];
+    a = __builtin_elementwise_fma(vp[0], f32x2{x0, x0}, a);
+    a = __builtin_elementwise_fma(vp[1], f32x2{x1, x1}, a);
+    a = __builtin_elementwise_fma(vp[2], f32x2{x2, x2}, a);
+    a = __builtin_elementwise_fma(vp[3], f32x2{x3, x3}, a);
+    a = __builtin_elementwise_fma(vp[4], f32x2{x4, x4}, a);
+    a = __builtin_elementwise_fma(vp[5], f32x2{x5, x5}, a);
+    a = __builtin_elementwise_fma(vp[6], f32x2{x6, x6}, a);
+    a = __builtin_elementwise_fma(vp[7], f32x2{x7, x7}, a);
+    acc[b] = a;
+  }
+}
+
+// Half-stage variant of the 4-bit step: one column PAIR at a time -- 16 lookups, then
+// their 8 packed FMAs -- so that only 16 lookup registers are live and the kernel fits 64 VGPRs
+// (four 8-wave workgroups per CU).
+template <int BT, int XL, int ABL>
+__device__ __forceinline__ void step4_half(const u32x4& slot, const float (&xslot)[BT], bool valid,
+                                           uint32_t lane_off, f32x2 (&acc)[2][BT]) {
+  uint32_t t[4] = {slot.x, slot.y, slot.z, slot.w};
+  SQLLM_PIN4(t[0], t[1], t[2], t[3]);
+  float xv[BT];
+#pragma unroll
+  for (int b = 0; b < BT; ++b) xv[b] = valid ? xslot[b] : 0.f;
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) {
+    f32x2 vp[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = 2 * jp + h;
+      const uint32_t lo = t[j] & 0x0F0F0F0Fu;
+      const uint32_t hi = (t[j] >> 4) & 0x0F0F0F0Fu;
+      const int off = jp * 4096 + h * 128;
+      float e[8];
+      e[0] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0400u) + off);
+      e[1] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0400u) + off);
+      e[2] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0500u) + off);
+      e[3] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0500u) + off);
+      e[4] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0600u) + off);
+      e[5] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0600u) + off);
+      e[6] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0700u) + off);
+      e[7] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0700u) + off);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (h) vp[i].y = e[i]; else vp[i].x = e[i];
+      }
+    }
+    fma_pair<BT, XL>(vp, xv, acc[jp]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int BT, int Q, int ABL, bool HALF = false>
 __device__ __forceinline__ void stage3(const uint32_t (&t0)[4], const uint32_t (&t1)[4], const uint32_t (&t2)[4],
                                        const uint32_t (&tb)[4], const float (&xlo)[BT], const float (&xhi)[BT],
                                        f32x2 (&acc)[2][BT]) {
+  if constexpr (HALF) {  // one column pair at a time: 16 live lookups (see step4_half)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      f32x2 vp[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = 2 * jp + h;
+        float e[8];
+        e[0] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 0>(t0[j], t1[j], t2[j]));
+        e[1] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 1>(t0[j], t1[j], t2[j]));
+        e[2] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 2>(t0[j], t1[j], t2[j]));
+        e[3] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 3>(t0[j], t1[j], t2[j]));
+        e[4] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 4>(t0[j], t1[j], t2[j]));
+        e[5] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 5>(t0[j], t1[j], t2[j]));
+        e[6] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 6>(t0[j], t1[j], t2[j]));
+        e[7] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 7>(t0[j], t1[j], t2[j]));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (h) vp[i].y = e[i]; else vp[i].x = e[i];
+        }
+      }
+      if constexpr (Q < 2) fma_pair<BT, 8 * Q>(vp, xlo, acc[jp]);
+      else fma_pair<BT, 8 * (Q - 2)>(vp, xhi, acc[jp]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
   float v[4][8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -261,7 +431,7 @@ __device__ __forceinline__ void stage3(const uint32_t (&t0)[4], const uint32_t (
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int BT, int ABL>
+template <int BT, int ABL, bool HALF = false>
 __device__ __forceinline__ void step3(const u32x4 (&slot)[3], const float (&xslot0)[BT], const float (&xslot1)[BT],
                                       bool valid, const uint32_t (&tb)[4], f32x2 (&acc)[2][BT]) {
   uint32_t t0[4] = {slot[0].x, slot[0].y, slot[0].z, slot[0].w};
@@ -276,10 +446,10 @@ __device__ __forceinline__ void step3(const u32x4 (&slot)[3], const float (&xslo
     xlo[b] = valid ? xslot0[b] : 0.f;
     xhi[b] = valid ? xslot1[b] : 0.f;
   }
-  stage3<BT, 0, ABL>(t0, t1, t2, tb, xlo, xhi, acc);
-  stage3<BT, 1, ABL>(t0, t1, t2, tb, xlo, xhi, acc);
-  stage3<BT, 2, ABL>(t0, t1, t2, tb, xlo, xhi, acc);
-  stage3<BT, 3, ABL>(t0, t1, t2, tb, xlo, xhi, acc);
+  stage3<BT, 0, ABL, HALF>(t0, t1, t2, tb, xlo, xhi, acc);
+  stage3<BT, 1, ABL, HALF>(t0, t1, t2, tb, xlo, xhi, acc);
+  stage3<BT, 2, ABL, HALF>(t0, t1, t2, tb, xlo, xhi, acc);
+  stage3<BT, 3, ABL, HALF>(t0, t1, t2, tb, xlo, xhi, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -466,7 +636,7 @@ __device__ __forceinline__ void dense_epilogue(const f32x2 (&acc)[2][BT], float*
 // address arithmetic cost more VALU than the overlap returns), and 16 waves per CU at different
 // phases keep the memory pipe busy.
 // ------------------------------------------------------------------------------------------------
-template <int BITS, int BT, int WAVES, int ABL, typename XT>
+template <int BITS, int BT, int WAVES, int ABL, typename XT, bool HALF = false>
 __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* __restrict__ y,
                                            const float* lut, int K, int N, int b0, int nb, int bid,
                                            int n_col_tiles, int units_total, int units_per_wg, float* lds,
@@ -483,7 +653,7 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   constexpr int ESTRIDE = (BITS == 4) ? 256 : 128;                 // bytes between consecutive entries
   constexpr int SUBB = (BITS == 4) ? (L * ESTRIDE) / 2 : L * ESTRIDE;  // LDS bytes per column sub-table
   // steps per chunk (4-bit: even, steps pair up for x; 3-bit: 12 VGPRs of weights per step)
-  constexpr int NBUF = (BITS == 4) ? (BT <= 4 ? 4 : 2) : (BT == 1 ? 2 : 1);
+  constexpr int NBUF = (BITS == 4) ? (BT <= 4 ? 4 : 2) : ((BT == 1 && !HALF) ? 2 : 1);
   constexpr int NXR = (BITS == 4) ? NBUF / 2 : 2 * NBUF;  // x registers per chunk and batch row
   constexpr int STEP = WAVES * 4;                // units a workgroup step covers
   const int tid = threadIdx.x;
@@ -656,18 +826,25 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   // u = this wave's (uniform) unit for the chunk's first step: guards are scalar branches; only the
   // per-row validity of a slice's ragged end is per lane (it zeroes x, no divergence)
   auto decode_chunk = [&](int u, const u32x4 (&w)[NBUF][R], const float (&xs)[NXR][BT]) {
-    if constexpr (BITS == 4) {
+    if constexpr (BITS == 4 && SQLLM_PIPE && !(ABL & 2)) {
+      decode4_pipelined<BT, NBUF, ABL>(w, xs, u, grp, u_end, STEP, lane_off, acc);
+    } else if constexpr (BITS == 4) {
 #pragma unroll
       for (int s2 = 0; s2 < NBUF / 2; ++s2) {
         const int ua = u + 2 * s2 * STEP, ub = ua + STEP;
-        if (ua < u_end) step4<BT, 0, ABL>(w[2 * s2][0], xs[s2], ua + grp < u_end, lane_off, acc);
-        if (ub < u_end) step4<BT, 8, ABL>(w[2 * s2 + 1][0], xs[s2], ub + grp < u_end, lane_off, acc);
+        if constexpr (HALF) {
+          if (ua < u_end) step4_half<BT, 0, ABL>(w[2 * s2][0], xs[s2], ua + grp < u_end, lane_off, acc);
+          if (ub < u_end) step4_half<BT, 8, ABL>(w[2 * s2 + 1][0], xs[s2], ub + grp < u_end, lane_off, acc);
+        } else {
+          if (ua < u_end) step4<BT, 0, ABL>(w[2 * s2][0], xs[s2], ua + grp < u_end, lane_off, acc);
+          if (ub < u_end) step4<BT, 8, ABL>(w[2 * s2 + 1][0], xs[s2], ub + grp < u_end, lane_off, acc);
+        }
       }
     } else {
 #pragma unroll
       for (int s = 0; s < NBUF; ++s) {
         const int ua = u + s * STEP;
-        if (ua < u_end) step3<BT, ABL>(w[s], xs[2 * s], xs[2 * s + 1], ua + grp < u_end, tb, acc);
+        if (ua < u_end) step3<BT, ABL, HALF>(w[s], xs[2 * s], xs[2 * s + 1], ua + grp < u_end, tb, acc);
       }
     }
   };
@@ -956,10 +1133,15 @@ __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
 // ------------------------------------------------------------------------------------------------
 // the fused kernel
 // ------------------------------------------------------------------------------------------------
+// Occupancy is what this kernel lives on (measured, DESIGN.md 4.1: thread-level parallelism beats
+// instruction-level parallelism here -- software-pipelining the stages at 104 VGPRs lost 8 %, while
+// halving the live lookups won up to 18 %): the decode stages work on one column pair at a time
+// (16 live lookups instead of 32), which lets the batch-1 kernels fit 64 VGPRs, i.e. FOUR 8-wave
+// workgroups per CU; the wider batch tiles take what they need up to 128 (two per CU).
 template <int BITS, int BT, int WAVES, int ABL, bool LIN>
-// occupancy target: 2 workgroups of 8 waves per CU (<= 128 VGPRs; every instantiation fits)
-__global__ void __launch_bounds__(WAVES * 64, (ABL & 64) ? 8 : 4)
+__global__ void __launch_bounds__(WAVES * 64, (ABL & 64) ? 8 : (BT == 1 ? 8 : 4))
 sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
+  constexpr bool HALF = SQLLM_HALF_STAGES && BT == 1;  // wider batch tiles: the per-row x broadcasts would be live twice
   constexpr int T = WAVES * 64;
   constexpr int kLds = lds_floats(Fmt<BITS>::kLut, WAVES, BT);
   __shared__ __attribute__((aligned(16))) float lds[kLds];
@@ -989,7 +1171,7 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
     sp = bid < gm.dense_block0 ? bid : -1;
   }
   if (d >= 0 && d < gm.dense_blocks) {
-    dense_role<BITS, BT, WAVES, ABL, XT>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, b0, nb,
+    dense_role<BITS, BT, WAVES, ABL, XT, HALF>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, b0, nb,
                                          d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds, sg, LIN ? &sg : nullptr);
   } else if (sp >= 0 && sp < gm.csr_blocks) {
     csr_role<T, BT, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds,

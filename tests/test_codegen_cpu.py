@@ -5,7 +5,8 @@ Each of these was a measured regression at some point of the build (DESIGN.md se
     and every later wait for a load degrades to vmcnt(0) -- including the dense role's codebook
     staging wait, which must leave the already issued weight loads in flight (+0.3-0.6 us/launch);
   * register spills / scratch in the decode loop;
-  * more than 128 VGPRs (two 8-wave workgroups per CU no longer fit).
+  * more than 64 VGPRs in the batch-1 kernels (four 8-wave workgroups per CU no longer fit: -18 % on
+    7B w3 s45) or more than 128 in the wider batch tiles.
 """
 import os
 import re
@@ -38,7 +39,8 @@ def _kernels(asm):
 
 def test_all_instantiations_present(asm):
     ks = _kernels(asm)
-    assert len(ks) == 16  # {3,4} bits x batch tile {1,2,4,8} x {operator, fused linear}
+    # {3,4} bits x batch tile {1,2,4,8} x {operator, fused linear}
+    assert len(ks) == 16
 
 
 def test_no_flat_memory_instructions(asm):
@@ -55,11 +57,12 @@ def test_codebook_staging_wait_leaves_the_weight_loads_in_flight(asm):
         assert waits and min(waits) >= 3, f"{name}: waits {waits} between the first weight load and the staging barrier"
 
 
-def test_no_spills_and_two_workgroups_per_cu(asm):
+def test_no_spills_and_occupancy_targets(asm):
     meta = re.findall(r"\.name:\s+(_ZN5sqllm18sqllm_fused_matvec\w+).*?\.private_segment_fixed_size:\s+(\d+).*?"
                       r"\.sgpr_spill_count:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", asm, re.S)
     assert len(meta) == 16
     for name, scratch, sspill, vgpr, vspill in meta:
         # (a few SGPRs parked in VGPR lanes are tolerated: no memory traffic; scratch is not)
         assert int(scratch) == 0 and int(vspill) == 0 and int(sspill) <= 16, (name, scratch, sspill, vspill)
-        assert int(vgpr) <= 128, (name, vgpr)
+        batch1 = re.search(r"matvecILi[34]ELi1E", name) is not None
+        assert int(vgpr) <= (64 if batch1 else 128), (name, vgpr)  # four / two 8-wave workgroups per CU
