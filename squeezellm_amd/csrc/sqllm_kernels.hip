@@ -1139,7 +1139,7 @@ __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
 // (16 live lookups instead of 32), which lets the batch-1 kernels fit 64 VGPRs, i.e. FOUR 8-wave
 // workgroups per CU; the wider batch tiles take what they need up to 128 (two per CU).
 template <int BITS, int BT, int WAVES, int ABL, bool LIN>
-__global__ void __launch_bounds__(WAVES * 64, (ABL & 64) ? 8 : (BT == 1 ? 8 : 4))
+__global__ void __launch_bounds__(WAVES * 64, (ABL & 64) ? 8 : ((BT == 1 && SQLLM_HALF_STAGES) ? 8 : 4))
 sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
   constexpr bool HALF = SQLLM_HALF_STAGES && BT == 1;  // wider batch tiles: the per-row x broadcasts would be live twice
   constexpr int T = WAVES * 64;
