@@ -58,7 +58,7 @@ int validate(const sqllm_op* op) {
 }
 
 // Launch geometry.  The dense part is cut into 64-column tiles x K slices so that about `target`
-// workgroups exist (2 per CU by default, 8 waves each = 16 waves per CU: the 7B shapes hold only
+// workgroups exist (1-3 per CU, 8 waves each, of the 4 that fit: the 7B shapes hold only
 // ~32-90 KiB of weights per CU, so the grid must be wide rather than deep).  A slice is a whole
 // number of workgroup steps (waves x 4 units) so only the last slice has a ragged end.
 void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm) {

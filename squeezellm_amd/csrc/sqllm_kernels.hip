@@ -633,7 +633,7 @@ __device__ __forceinline__ void dense_epilogue(const f32x2 (&acc)[2][BT], float*
 // A wave issues the loads of a chunk of NBUF steps back to back, then decodes them in arrival
 // order (counted vmcnt waits), then loops.  In-flight loads are deliberately NOT carried around
 // the loop edge: the kernel is VALU-bound, deeper pipelines measured slower (their copies and
-// address arithmetic cost more VALU than the overlap returns), and 16 waves per CU at different
+// address arithmetic cost more VALU than the overlap returns), and up to 32 waves per CU at different
 // phases keep the memory pipe busy.
 // ------------------------------------------------------------------------------------------------
 template <int BITS, int BT, int WAVES, int ABL, typename XT, bool HALF = false>
