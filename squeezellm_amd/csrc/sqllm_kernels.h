@@ -3,9 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef SQLLM_WAVES
+#define SQLLM_WAVES 8  // waves per workgroup (measurement builds: 4)
+#endif
+
 namespace sqllm {
 
-constexpr int kWaves = 8;          // waves per workgroup (512 threads)
+constexpr int kWaves = SQLLM_WAVES;          // waves per workgroup (512 threads)
 constexpr int kTileN = 64;         // output columns per dense tile = 16 lanes x 4 (one dwordx4 each)
 constexpr int kCsrChunk = 1024;    // non-zeros per CSR workgroup
 constexpr int kCsrSpanMax = 2048;  // CSR rows a chunk may span and still accumulate in LDS

@@ -748,9 +748,12 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
     if (c > N - 1) c = N - 1;
     const float* src = lut + (size_t)c * L;
     if constexpr (BITS == 4) {
-      static_assert(EPW == 4, "4-bit staging assumes 8 waves: one float4 per thread");
-      const f32x4 t = *reinterpret_cast<const f32x4*>(src + st_h * EPW);
-      ev[0] = t.x; ev[1] = t.y; ev[2] = t.z; ev[3] = t.w;
+      static_assert(EPW % 4 == 0, "4-bit staging loads whole float4s");
+#pragma unroll
+      for (int i = 0; i < EPW / 4; ++i) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + st_h * EPW + 4 * i);
+        ev[4 * i] = t.x; ev[4 * i + 1] = t.y; ev[4 * i + 2] = t.z; ev[4 * i + 3] = t.w;
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < RPW; ++i) ev[i] = src[2 * (st_h * RPW + i) + (lane >> 5)];
