@@ -203,3 +203,36 @@ def test_linear_counts_every_kind_of_sparse_contribution(gpu, bits, rows):
     for _ in range(2):
         _check_fp16(mod(x).reshape(rows, N).cpu().numpy(), exact)
     assert int(next(iter(mod._ws.values())).count_nonzero()) == 0
+
+
+def test_linears_on_one_stream_may_share_a_workspace(gpu):
+    """include/sqllm_hip.h: "launches on one stream may share it".  Two different layers (same N)
+    alternate on one workspace, back to back, no synchronisation in between."""
+    import torch
+
+    from squeezellm_amd import _lib, synth
+
+    K, N = 2048, 1024
+    lays = [synth.make_layer(K, N, b, sparse_frac=0.004, topX=4, heavy_rows=2, bias=True, device=gpu, seed=40 + b) for b in (3, 4)]
+    xs = [torch.randn(K, device=gpu).half() for _ in lays]
+    outs = [torch.empty(N, device=gpu, dtype=torch.float16) for _ in lays]
+    ws = torch.zeros(_lib.linear_workspace_bytes(N, 0), dtype=torch.uint8, device=gpu)
+    lins = []
+    for lay, x, out in zip(lays, xs, outs):
+        lin = _lib.SqllmLinear()
+        o = lin.op
+        o.bits, o.batch, o.K, o.N = lay["bits"], 0, K, N
+        o.vec, o.qweight, o.mul, o.lookup_table = x.data_ptr(), lay["qweight"].data_ptr(), out.data_ptr(), lay["lookup_table"].data_ptr()
+        o.rows, o.cols, o.vals, o.nnz = lay["rows"].data_ptr(), lay["cols"].data_ptr(), lay["vals"].data_ptr(), lay["vals"].numel()
+        o.full_rows, o.full_row_indices, o.topX = lay["full_rows"].data_ptr(), lay["full_row_indices"].data_ptr(), 4
+        lin.bias, lin.workspace = lay["bias"].data_ptr(), ws.data_ptr()
+        lins.append(lin)
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        for lin in lins:
+            assert lib.sqllm_linear_f16(ctypes.byref(lin), stream) == 0
+    torch.cuda.synchronize()
+    for lay, x, out in zip(lays, xs, outs):
+        _check_fp16(out.cpu().numpy().reshape(1, N), _exact(_npl(lay), x.cpu().numpy().reshape(1, K), "hybrid"))
+    assert int(ws.count_nonzero()) == 0
