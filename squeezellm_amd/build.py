@@ -48,6 +48,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     extra = ["-DSQLLM_ABLATION_BUILD"] if os.environ.get("SQLLM_ABLATION") == "1" else []
     if os.environ.get("SQLLM_WAVES"):  # measurement builds: waves per workgroup (default 8)
         extra.append("-DSQLLM_WAVES=" + str(int(os.environ["SQLLM_WAVES"])))
+    if os.environ.get("SQLLM_PAIR3"):  # measurement builds: 0 = 3-bit decode with one lookup per weight
+        extra.append("-DSQLLM_PAIR3=" + str(int(os.environ["SQLLM_PAIR3"])))
     if os.environ.get("SQLLM_HALF_STAGES"):  # measurement builds: 0 = whole-stage decode (32 live lookups)
         extra.append("-DSQLLM_HALF_STAGES=" + str(int(os.environ["SQLLM_HALF_STAGES"])))
     if os.environ.get("SQLLM_PIPE"):  # measurement builds: software-pipelined 4-bit chunk decode

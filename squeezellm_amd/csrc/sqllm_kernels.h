@@ -26,8 +26,10 @@ constexpr int kMaxContrib = 511;   // fused linear: contributions one column may
 //   csr  : kCsrSpanMax ints + kCsrSpanMax floats
 //   topx : kTopxLds
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
-constexpr int lds_floats(int lut_entries, int waves, int bt) {
-  return cmax(4 * lut_entries * 32 + waves * bt * kTileN + 4 + bt * kTileN, cmax(2 * kCsrSpanMax, kTopxLds));
+constexpr int lds_floats(int lut_entries, int waves, int bt, bool pair3 = false) {
+  // pair3: the 3-bit batch-1 kernels stage 64-entry PAIR tables, 4 x 64 x 128 B per tile
+  return cmax((pair3 ? 4 * 64 * 32 : 4 * lut_entries * 32) + waves * bt * kTileN + 4 + bt * kTileN,
+              cmax(2 * kCsrSpanMax, kTopxLds));
 }
 
 // Launch geometry, computed on the host (sqllm_capi.hip: make_plan) and passed by value.

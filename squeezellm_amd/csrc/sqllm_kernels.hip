@@ -51,6 +51,9 @@
 #ifndef SQLLM_PIPE
 #define SQLLM_PIPE 0
 #endif
+#ifndef SQLLM_PAIR3
+#define SQLLM_PAIR3 1  // 0 (measurement builds): 3-bit batch-1 decode with one lookup per weight
+#endif
 #ifndef SQLLM_HALF_STAGES
 #define SQLLM_HALF_STAGES 1  // 0 (measurement builds): whole-stage decode, 32 live lookups
 #endif
@@ -453,6 +456,88 @@ __device__ __forceinline__ void step3(const u32x4 (&slot)[3], const float (&xslo
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3-bit PAIR decode (SQLLM_PAIR3; batch tile 1): the kernel is bound by the SUM of its vector and
+// LDS instructions, and the plain 3-bit path spends 4.1 of them per weight.
+// Here a column's codebook is staged as a 64-entry table of PAIRS -- entry i0 + 8 * i1 holds
+// (lut[i0], lut[i1]) -- so that one ds_read_b64, addressed by the 6-bit field of two consecutive
+// weights (k, k+1), returns both values, and one packed FMA multiplies them by (x[k], x[k+1]):
+// 2 address ops + 1 lookup + 1 FMA + 1/2 broadcast per TWO weights.  The accumulator of a column
+// is a float2 (even k, odd k), summed at the end.  32 KB of tables per 64-column tile.
+// ------------------------------------------------------------------------------------------------
+template <int M>  // pair M of a unit: weights k = 2M, 2M+1 = bits [6M, 6M+6) of the 96-bit stream; result << 7
+__device__ __forceinline__ uint32_t field6_x128(uint32_t t0, uint32_t t1, uint32_t t2) {
+  constexpr int bit = 6 * M;
+  constexpr int w = bit >> 5;
+  constexpr int o = bit & 31;
+  const uint32_t lo = (w == 0) ? t0 : (w == 1) ? t1 : t2;
+  uint32_t f;
+  if constexpr (o <= 26) {
+    if constexpr (o > 7) f = lo >> (o - 7);
+    else if constexpr (o < 7) f = lo << (7 - o);
+    else f = lo;
+  } else {  // pairs 5 and 10 straddle a dword boundary
+    const uint32_t hi = (w == 0) ? t1 : t2;
+    f = __builtin_amdgcn_alignbit(hi, lo, o) << 7;
+  }
+  return f & 0x1F80u;
+}
+
+__device__ __forceinline__ f32x2 lds_read_f32x2(uint32_t byte_addr) {
+  return *reinterpret_cast<const f32x2 __attribute__((address_space(3)))*>(byte_addr);
+}
+
+// 8 pairs (16 k's) of ONE column: 8 lookups live at a time
+template <int H>
+__device__ __forceinline__ void stage3_pair(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t tbj,
+                                            const float (&xb)[16], f32x2& acc) {
+  f32x2 v[8];
+  v[0] = lds_read_f32x2(tbj | field6_x128<8 * H + 0>(t0, t1, t2));
+  v[1] = lds_read_f32x2(tbj | field6_x128<8 * H + 1>(t0, t1, t2));
+  v[2] = lds_read_f32x2(tbj | field6_x128<8 * H + 2>(t0, t1, t2));
+  v[3] = lds_read_f32x2(tbj | field6_x128<8 * H + 3>(t0, t1, t2));
+  v[4] = lds_read_f32x2(tbj | field6_x128<8 * H + 4>(t0, t1, t2));
+  v[5] = lds_read_f32x2(tbj | field6_x128<8 * H + 5>(t0, t1, t2));
+  v[6] = lds_read_f32x2(tbj | field6_x128<8 * H + 6>(t0, t1, t2));
+  v[7] = lds_read_f32x2(tbj | field6_x128<8 * H + 7>(t0, t1, t2));
+  f32x2 a = acc;
+  a = __builtin_elementwise_fma(v[0], f32x2{xb[0], xb[1]}, a);
+  a = __builtin_elementwise_fma(v[1], f32x2{xb[2], xb[3]}, a);
+  a = __builtin_elementwise_fma(v[2], f32x2{xb[4], xb[5]}, a);
+  a = __builtin_elementwise_fma(v[3], f32x2{xb[6], xb[7]}, a);
+  a = __builtin_elementwise_fma(v[4], f32x2{xb[8], xb[9]}, a);
+  a = __builtin_elementwise_fma(v[5], f32x2{xb[10], xb[11]}, a);
+  a = __builtin_elementwise_fma(v[6], f32x2{xb[12], xb[13]}, a);
+  a = __builtin_elementwise_fma(v[7], f32x2{xb[14], xb[15]}, a);
+  acc = a;
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void step3_pair(const u32x4 (&slot)[3], float xslot0, float xslot1, bool valid,
+                                           const uint32_t (&tb)[4], f32x2 (&accp)[4]) {
+  uint32_t t0[4] = {slot[0].x, slot[0].y, slot[0].z, slot[0].w};
+  uint32_t t1[4] = {slot[1].x, slot[1].y, slot[1].z, slot[1].w};
+  uint32_t t2[4] = {slot[2].x, slot[2].y, slot[2].z, slot[2].w};
+  SQLLM_PIN4(t0[0], t0[1], t0[2], t0[3]);
+  SQLLM_PIN4(t1[0], t1[1], t1[2], t1[3]);
+  SQLLM_PIN4(t2[0], t2[1], t2[2], t2[3]);
+  const float xlo = valid ? xslot0 : 0.f, xhi = valid ? xslot1 : 0.f;
+#define SQLLM_XB16(X) {row_bcast<0>(X), row_bcast<1>(X), row_bcast<2>(X), row_bcast<3>(X), row_bcast<4>(X), row_bcast<5>(X), \
+                       row_bcast<6>(X), row_bcast<7>(X), row_bcast<8>(X), row_bcast<9>(X), row_bcast<10>(X), row_bcast<11>(X), \
+                       row_bcast<12>(X), row_bcast<13>(X), row_bcast<14>(X), row_bcast<15>(X)}
+  {
+    const float xb[16] = SQLLM_XB16(xlo);  // x of k = 0..15 of the unit, broadcast along the 16-lane row
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stage3_pair<0>(t0[j], t1[j], t2[j], tb[j], xb, accp[j]);
+  }
+  {
+    const float xb[16] = SQLLM_XB16(xhi);  // k = 16..31
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stage3_pair<1>(t0[j], t1[j], t2[j], tb[j], xb, accp[j]);
+  }
+#undef SQLLM_XB16
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused-linear completion (sqllm_linear_f16: fp16 in, fp16 out, bias, no launches around the op --
 // the reference wraps every op in a zeros/clone, an x.float() and a y.to(fp16) kernel,
 // squeezellm/quant.py:214-223,311-312).
@@ -650,6 +735,8 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   __builtin_amdgcn_s_waitcnt(0);
   constexpr int L = F::kLut;
   constexpr int R = F::kRows;
+  constexpr bool PAIR = BITS == 3 && HALF && SQLLM_PAIR3;          // 3-bit pair tables (batch tile 1)
+  static_assert(!PAIR || (WAVES == 8 && BT == 1), "pair tables: wave w stages second index w");
   constexpr int ESTRIDE = (BITS == 4) ? 256 : 128;                 // bytes between consecutive entries
   constexpr int SUBB = (BITS == 4) ? (L * ESTRIDE) / 2 : L * ESTRIDE;  // LDS bytes per column sub-table
   // steps per chunk (4-bit: even, steps pair up for x; 3-bit: 12 VGPRs of weights per step)
@@ -739,15 +826,22 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   //          wave w stages column j = w % 4, pairs [(w / 4) * RPW, + RPW), RPW = 16 / WAVES.
   constexpr int EPW = 32 / WAVES;                       // 4-bit: entries per wave
   constexpr int RPW = 16 / WAVES;                       // 3-bit: entry pairs per wave
-  constexpr int NE = (BITS == 4) ? EPW : RPW;           // codebook values this thread stages
+  constexpr int NE = PAIR ? 9 : (BITS == 4) ? EPW : RPW;  // codebook values this thread stages
   float ev[NE];
   const int st_j = (BITS == 4) ? 2 * (wave & 1) + (lane >> 5) : (wave & 3);  // column this lane stages
   const int st_h = (BITS == 4) ? (wave >> 1) : (wave >> 2);
   if constexpr (!(ABL & 4)) {
-    int c = col0 + 4 * i16 + st_j;
+    int c = col0 + 4 * i16 + (PAIR ? grp : st_j);
     if (c > N - 1) c = N - 1;
     const float* src = lut + (size_t)c * L;
-    if constexpr (BITS == 4) {
+    if constexpr (PAIR) {
+      // thread = (slot i16, lane column grp, second index = wave): all 8 entries of its column,
+      // plus the one that is the second element of every pair it writes
+      const f32x4 ta = *reinterpret_cast<const f32x4*>(src), tb4 = *reinterpret_cast<const f32x4*>(src + 4);
+      ev[0] = ta.x; ev[1] = ta.y; ev[2] = ta.z; ev[3] = ta.w;
+      ev[4] = tb4.x; ev[5] = tb4.y; ev[6] = tb4.z; ev[7] = tb4.w;
+      ev[8] = src[wave];
+    } else if constexpr (BITS == 4) {
       static_assert(EPW % 4 == 0, "4-bit staging loads whole float4s");
 #pragma unroll
       for (int i = 0; i < EPW / 4; ++i) {
@@ -776,7 +870,7 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
 #endif
   // Branches first: between the loads below and the codebook staging there must be NO control
   // flow, or the staging waits for every outstanding load (vmcnt(0)) instead of its own.
-  constexpr int kCodebookFloats = 4 * SUBB / 4;  // the four column sub-tables
+  constexpr int kCodebookFloats = PAIR ? 4 * 64 * 128 / 4 : 4 * SUBB / 4;  // the four column sub-tables
   float* topx_sum = lds + kCodebookFloats + WAVES * BT * kTileN + 4;  // [BT][64], fused linear only
   // epilogue ticket (the dword after the slabs) and, 4 dwords on, the BT * 64 top-X sums
   for (int i = tid; i < 4 + BT * kTileN; i += WAVES * 64) lds[kCodebookFloats + WAVES * BT * kTileN + i] = 0.f;
@@ -796,7 +890,12 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
 
   // ---- stage the codebooks (row-wise, see above) ----
   if constexpr (!(ABL & 4)) {
-    if constexpr (BITS == 4) {
+    if constexpr (PAIR) {
+      // sub-table of lane column j: 64 entry rows of 128 B (16 slots x 8 B); entry i0 + 8 * wave
+      char* dst = reinterpret_cast<char*>(lds) + grp * 8192 + wave * 8 * 128 + i16 * 8;
+#pragma unroll
+      for (int i0 = 0; i0 < 8; ++i0) *reinterpret_cast<f32x2*>(dst + i0 * 128) = f32x2{ev[i0], ev[8]};
+    } else if constexpr (BITS == 4) {
       // row (pair, idx) starts at pair * 4096 + idx * 256; this lane's dword in it is `lane`
       float* dst = lds + ((wave & 1) * 4096 + st_h * EPW * ESTRIDE) / 4 + lane;
 #pragma unroll
@@ -819,7 +918,8 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   const uint32_t lane_off = 4 * (i16 + 16 * (grp & 1));  // 4-bit: dword slot inside a 128-byte half row
   uint32_t tb[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) tb[j] = j * SUBB + 4 * (i16 + 16 * (grp & 1));
+  for (int j = 0; j < 4; ++j) tb[j] = PAIR ? j * 8192 + 8 * i16 : j * SUBB + 4 * (i16 + 16 * (grp & 1));
+  f32x2 accp[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};  // PAIR: (even k, odd k) per column
 
   __syncthreads();  // codebooks visible
 #ifdef SQLLM_ABLATION_BUILD
@@ -847,7 +947,11 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
 #pragma unroll
       for (int s = 0; s < NBUF; ++s) {
         const int ua = u + s * STEP;
-        if (ua < u_end) step3<BT, ABL, HALF>(w[s], xs[2 * s], xs[2 * s + 1], ua + grp < u_end, tb, acc);
+        if constexpr (PAIR) {
+          if (ua < u_end) step3_pair(w[s], xs[2 * s][0], xs[2 * s + 1][0], ua + grp < u_end, tb, accp);
+        } else {
+          if (ua < u_end) step3<BT, ABL, HALF>(w[s], xs[2 * s], xs[2 * s + 1], ua + grp < u_end, tb, acc);
+        }
       }
     }
   };
@@ -893,6 +997,10 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
   if (tl && lane == 0) tl[4 + (wave & 3)] = __builtin_amdgcn_s_memrealtime();  // decode end of waves 0-3
 #endif
+  if constexpr (PAIR) {
+    acc[0][0] = f32x2{accp[0].x + accp[0].y, accp[1].x + accp[1].y};
+    acc[1][0] = f32x2{accp[2].x + accp[2].y, accp[3].x + accp[3].y};
+  }
   dense_epilogue<BT, WAVES, ABL>(acc, lds + kCodebookFloats, topx_sum, fold_topx, y, N, col0, b0, nb, lane, wave, sg, lin
 #ifdef SQLLM_ABLATION_BUILD
                                  , tl
@@ -1146,7 +1254,7 @@ __global__ void __launch_bounds__(WAVES * 64, (ABL & 64) ? 8 : ((BT == 1 && SQLL
 sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
   constexpr bool HALF = SQLLM_HALF_STAGES && BT == 1;  // wider batch tiles: the per-row x broadcasts would be live twice
   constexpr int T = WAVES * 64;
-  constexpr int kLds = lds_floats(Fmt<BITS>::kLut, WAVES, BT);
+  constexpr int kLds = lds_floats(Fmt<BITS>::kLut, WAVES, BT, BITS == 3 && BT == 1 && SQLLM_HALF_STAGES && SQLLM_PAIR3);
   __shared__ __attribute__((aligned(16))) float lds[kLds];
   using XT = typename XType<LIN>::type;
   using AT = typename AccType<LIN>::type;
