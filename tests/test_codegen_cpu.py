@@ -66,3 +66,17 @@ def test_no_spills_and_occupancy_targets(asm):
         assert int(scratch) == 0 and int(vspill) == 0 and int(sspill) <= 16, (name, scratch, sspill, vspill)
         batch1 = re.search(r"matvecILi[34]ELi1E", name) is not None
         assert int(vgpr) <= (64 if batch1 else 128), (name, vgpr)  # four / two 8-wave workgroups per CU
+
+
+def test_three_bit_batch1_decode_uses_pair_lookups(asm):
+    """The 3-bit batch-1 kernels look two weights up with ONE ds_read_b64 (64-entry pair tables,
+    DESIGN.md 4.1): per 32-k unit and column 16 eight-byte lookups and 16 packed FMAs, and no
+    four-byte lookups left in the decode."""
+    for name, body in _kernels(asm).items():
+        if not re.search(r"matvecILi3ELi1E", name):
+            continue
+        b64 = sum(1 for l in body if re.match(r"\s+ds_read_b64", l))
+        b32 = sum(1 for l in body if re.match(r"\s+ds_read_b32", l))
+        pk = sum(1 for l in body if re.match(r"\s+v_pk_fma_f32", l))
+        assert b64 >= 128 and pk >= 128, (name, b64, pk)  # two copies of the step (first chunk + loop) x 64
+        assert b32 <= 16, (name, b32)                       # epilogue / sparse roles only
