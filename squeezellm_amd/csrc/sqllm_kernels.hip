@@ -35,8 +35,14 @@
 //     weight, quant_cuda_kernel.cu:866).
 //   * partial sums are folded across the 4 lane rows with two cross-lane adds, across the waves
 //     through LDS, and leave the workgroup as one atomic per column.
-//   * no MFMA: batch-1 decode is a memory-bound gather; the ceilings are HBM, then LDS lookup
-//     issue (one ds_read_b32 per weight, 32 per clock per CU), then VALU.
+//   * no MFMA: batch-1 decode is a gather.  What bounds it (measured) is
+//     instruction issue: a SIMD starts one wave64 instruction per four cycles, vector OR LDS, so
+//     a weight costs the sum of both (4-bit: 2.4 + 1.1).  Two consequences shape the code:
+//       - occupancy over ILP: decode stages work on one column pair at a time (16 live lookups),
+//         the batch-1 kernels fit 64 VGPRs and run four 8-wave workgroups per CU;
+//       - fewer instructions per weight where the format allows it: 3-bit codebooks are staged as
+//         64-entry tables of PAIRS and two consecutive weights cost one ds_read_b64 + one packed
+//         FMA (2.45 instructions per weight instead of 4.1).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
