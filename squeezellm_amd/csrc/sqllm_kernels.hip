@@ -1224,6 +1224,47 @@ __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
   if (k1 > K) k1 = K;
   const int nel = (k1 - k0) * topX;
   const float* fr = full_rows + (size_t)k0 * topX;
+  if (topX <= 16) {
+    // The usual case (the reference uses topX = 10).  Lane l of a 16-lane row owns column l (lanes
+    // >= topX idle) and the 32 lane rows of the workgroup take k0 + row, + 32, + 64, + 96: a wave
+    // reads 4 consecutive rows of the slab (contiguous), every thread keeps ONE partial sum in a
+    // register, two cross-lane adds fold the wave's 4 lane rows, the 8 waves meet in LDS through
+    // plain stores.  No LDS atomics (64 lanes on 10 addresses execute one lane at a time: that and
+    // two more barriers cost 0.6-0.9 us on the grouped 7B launches), one barrier per batch row.
+    static_assert(T == 512, "32 lane rows x 4 k's cover the 128-k slab");
+    const int c = tid & 15, krow = tid >> 4;  // krow 0..31
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool live = c < topX;
+    float frv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int k = k0 + krow + 32 * i;
+      if (k > k1 - 1) k = k1 - 1;  // clamped re-read, masked below
+      frv[i] = live ? full_rows[(size_t)k * topX + c] : 0.f;
+    }
+    const int dst = live ? full_idx[c] : 0;
+    for (int b = 0; b < nb; ++b) {
+      const XT* xb = x + (size_t)(b0 + b) * K;
+      float p = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = k0 + krow + 32 * i;
+        p = __builtin_fmaf(frv[i], k < k1 ? (float)xb[k] : 0.f, p);
+      }
+      p += __shfl_xor(p, 16, 64);
+      p += __shfl_xor(p, 32, 64);
+      if (b > 0) __syncthreads();  // the previous batch row's sums have been read
+      if (lane < 16) lds[wave * 16 + lane] = p;
+      __syncthreads();
+      if (tid < topX) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < T / 64; ++w) sum += lds[w * 16 + tid];
+        acc_add(y + (size_t)(b0 + b) * N + dst, sum);
+      }
+    }
+    return;
+  }
   const bool in_lds = topX <= kTopxLds;
   float* sacc = lds;
   for (int b = 0; b < nb; ++b) {
