@@ -61,7 +61,7 @@ int validate(const sqllm_op* op) {
 // workgroups exist (1-3 per CU, 8 waves each, of the 4 that fit: the 7B shapes hold only
 // ~32-90 KiB of weights per CU, so the grid must be wide rather than deep).  A slice is a whole
 // number of workgroup steps (waves x 4 units) so only the last slice has a ragged end.
-void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm) {
+void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1) {
   const int kK = (op->bits == 4) ? 8 : 32;
   memset(gm, 0, sizeof(*gm));
   gm->K = op->K;
@@ -74,10 +74,13 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm) {
   if (upw <= 0) {
     int target = g_target_wgs.load(std::memory_order_relaxed);
     if (target <= 0) {
-      // measured on MI355X (tools/sweep.py, bench.py): layers under ~12 MB of packed weights run
-      // best with one 8-wave workgroup per CU, larger ones with ~3 per CU
+      // measured on MI355X (tools/sweep.py, bench.py): an op under ~12 MB of packed weights runs
+      // best with one 8-wave workgroup per CU when it shares its launch with others (q/k/v) and
+      // with two when it is alone (o_proj); larger ones with ~3 per CU (gate/up) or 4 when alone
+      // (down_proj) -- the chip holds four per CU
       const double mb = (double)op->K * op->N * op->bits / 8.0 / 1e6;
-      target = mb <= 12.0 ? cu_count() : 3 * cu_count();
+      const bool alone = ops_in_launch <= 1;
+      target = (mb <= 12.0 ? (alone ? 2 : 1) : (alone ? 4 : 3)) * cu_count();
     }
     int slices = (target + gm->col_tiles / 2) / gm->col_tiles;
     if (slices < 1) slices = 1;
@@ -223,7 +226,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
 #ifdef SQLLM_ABLATION_BUILD
     if (!lin) sg.bias = static_cast<const float*>(g_timeline.load(std::memory_order_relaxed));
 #endif
-    make_plan(op, &sg.gm);
+    make_plan(op, &sg.gm, n);
     if (lin) {
       // accumulate into the workspace plane; op->mul is the fp16 result
       sg.y = reinterpret_cast<float*>(lin[i].workspace);
