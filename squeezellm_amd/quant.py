@@ -125,11 +125,17 @@ class QuantLinearLUTFused(QuantLinearLUT):
     parent's path."""
 
     def _workspace(self, batch: int, device) -> torch.Tensor:
+        """ONE zero-filled workspace per device, sized for the largest batch seen so far: a launch
+        uses the first 8 * batch * N bytes and leaves them zero-filled, so smaller batches reuse
+        the same buffer (a cache keyed by batch size would grow without bound under variable
+        prompt lengths)."""
         cache = self.__dict__.setdefault("_ws", {})
-        key = (batch, device)
-        if key not in cache:  # zero-filled once; every launch leaves it zero-filled
-            cache[key] = torch.zeros(_lib.linear_workspace_bytes(self.outfeatures, batch), dtype=torch.uint8, device=device)
-        return cache[key]
+        need = _lib.linear_workspace_bytes(self.outfeatures, batch)
+        ws = cache.get(device)
+        if ws is None or ws.numel() < need:
+            ws = torch.zeros(need, dtype=torch.uint8, device=device)  # zero-filled once
+            cache[device] = ws
+        return ws
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dtype != torch.float16 or not x.is_cuda:

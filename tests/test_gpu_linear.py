@@ -236,3 +236,26 @@ def test_linears_on_one_stream_may_share_a_workspace(gpu):
     for lay, x, out in zip(lays, xs, outs):
         _check_fp16(out.cpu().numpy().reshape(1, N), _exact(_npl(lay), x.cpu().numpy().reshape(1, K), "hybrid"))
     assert int(ws.count_nonzero()) == 0
+
+
+def test_fused_forward_keeps_one_workspace_across_batch_sizes(gpu):
+    """Variable prompt lengths must not grow a cache: one zero-filled buffer per device, sized for
+    the largest batch seen, whose prefix serves the smaller ones."""
+    import torch
+
+    from squeezellm_amd import quant, synth
+
+    K, N = 512, 200
+    lay = synth.make_layer(K, N, 4, sparse_frac=0.01, topX=3, heavy_rows=1, bias=True, device=gpu, seed=123)
+    mod = quant.QuantLinearLUT.from_operands(lay)
+    mod.__class__ = quant.QuantLinearLUTFused
+    npl = _npl(lay)
+    sizes = []
+    for rows in (8, 3, 1, 12, 5, 12, 1):
+        x = torch.randn((rows, K), device=gpu).half()
+        y = mod(x if rows > 1 else x.reshape(1, 1, K)).reshape(rows, N)
+        _check_fp16(y.cpu().numpy(), _exact(npl, x.cpu().numpy(), "hybrid"))
+        assert len(mod._ws) == 1
+        sizes.append(next(iter(mod._ws.values())).numel())
+        assert int(next(iter(mod._ws.values())).count_nonzero()) == 0
+    assert sizes == sorted(sizes) and sizes[-1] == 8 * 12 * N
