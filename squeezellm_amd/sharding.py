@@ -105,7 +105,7 @@ class DecodeStage:
             if l["N"] == hidden:
                 self.out_idx = i
         self.ys = ys
-        self.seq = OpSequence(list(layers), xs, ys) if layers else None
+        self.seq = OpSequence(list(layers), xs, ys, fuse_shared_input=True) if layers else None
 
     def __call__(self, h_in: torch.Tensor) -> torch.Tensor:
         if self.seq is None or self.out_idx is None:
