@@ -19,6 +19,7 @@ std::atomic<int> g_cu_count{0};
 std::atomic<int> g_ablate{0};
 std::atomic<int> g_sparse_last{0};
 std::atomic<int> g_ablate_csr{0};
+std::atomic<int> g_mfma_min_batch{6};  // *_batched ops with at least this many rows take the matrix-core kernel
 std::atomic<void*> g_timeline{nullptr};  // measurement build: per-workgroup timestamp buffer
 
 int cu_count() {
@@ -106,6 +107,36 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1)
 #endif
 }
 
+// Geometry of the wide-batch (matrix-core) kernel: one pass covers 16 * mb batch rows (blockIdx.y
+// walks the passes); the K slices are cut so that about 2 workgroups per CU exist in total (measured
+// flat between 2 and 5 slices; fewer slices = fewer atomics per output); a slice is a whole number
+// of workgroup steps (waves x 4 units), as in make_plan.
+void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm) {
+  make_plan(op, gm, 1);
+  const int mb = sqllm::mfma_row_blocks(gm->batch);
+  const int grid_y = (gm->batch + 16 * mb - 1) / (16 * mb);
+  const int step = sqllm::kWaves * 4;
+  int upw = g_groups_per_wave.load(std::memory_order_relaxed) * sqllm::kWaves;
+  if (upw <= 0) {
+    int target = g_target_wgs.load(std::memory_order_relaxed);
+    if (target <= 0) target = 2 * cu_count();
+    int slices = (target + gm->col_tiles * grid_y - 1) / (gm->col_tiles * grid_y);
+    if (slices < 1) slices = 1;
+    if (slices > sqllm::kMaxSlices) slices = sqllm::kMaxSlices;
+    upw = (gm->units_total + slices - 1) / slices;
+  }
+  upw = (upw + step - 1) / step * step;
+  gm->units_per_wg = upw;
+  gm->k_slices = (gm->units_total + upw - 1) / upw;
+  gm->dense_blocks = gm->col_tiles * gm->k_slices;
+  gm->sparse_last = 0;
+  gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
+}
+
+bool takes_mfma_path(const sqllm_op* op) {
+  return op->batch >= 1 && op->batch >= g_mfma_min_batch.load(std::memory_order_relaxed);
+}
+
 }  // namespace
 
 extern "C" {
@@ -140,6 +171,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "groups_per_wave")) { g_groups_per_wave.store(value); return SQLLM_OK; }
   if (!strcmp(name, "sparse_last")) { g_sparse_last.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { g_cu_count.store(value); return SQLLM_OK; }  // for GPU-less planning tests
+  if (!strcmp(name, "mfma_min_batch")) { g_mfma_min_batch.store(value < 1 ? 1 : value); return SQLLM_OK; }
 #ifdef SQLLM_ABLATION_BUILD
   if (!strcmp(name, "ablate")) { g_ablate.store(value); return SQLLM_OK; }
   if (!strcmp(name, "ablate_csr")) { g_ablate_csr.store(value); return SQLLM_OK; }
@@ -152,6 +184,7 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "target_wgs")) { *value = g_target_wgs.load(); return SQLLM_OK; }
   if (!strcmp(name, "groups_per_wave")) { *value = g_groups_per_wave.load(); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { *value = g_cu_count.load(); return SQLLM_OK; }
+  if (!strcmp(name, "mfma_min_batch")) { *value = g_mfma_min_batch.load(); return SQLLM_OK; }
   return SQLLM_E_OPTION;
 }
 
@@ -162,7 +195,9 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   if (op->bits != 3 && op->bits != 4) return SQLLM_E_BITS;
   if (op->K <= 0 || op->N <= 0 || (op->K % 32) != 0 || (op->N % 4) != 0) return SQLLM_E_SHAPE;
   sqllm::KernelGeom gm;
-  make_plan(op, &gm);
+  const bool mfma = takes_mfma_path(op);
+  if (mfma) make_plan_mfma(op, &gm);
+  else make_plan(op, &gm);
   plan->col_tiles = gm.col_tiles;
   plan->k_slices = gm.k_slices;
   plan->groups_per_wave = gm.units_per_wg;
@@ -170,7 +205,8 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   plan->csr_blocks = gm.csr_blocks;
   plan->topx_blocks = gm.topx_blocks;
   plan->grid_x = gm.dense_block0 + gm.dense_blocks;
-  plan->grid_y = (gm.batch + sqllm::batch_tile(gm.batch) - 1) / sqllm::batch_tile(gm.batch);
+  const int rows_per_pass = mfma ? 16 * sqllm::mfma_row_blocks(gm.batch) : sqllm::batch_tile(gm.batch);
+  plan->grid_y = (gm.batch + rows_per_pass - 1) / rows_per_pass;
   return SQLLM_OK;
 }
 
@@ -188,6 +224,38 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
                                     hipEvent_t e1, const sqllm_linear* lin = nullptr) {
   if (n < 1 || n > sqllm::kMaxSegments) return SQLLM_E_GROUP;
   if (!ops && !lin) return SQLLM_E_NULL;
+  if (!lin && takes_mfma_path(&ops[0])) {
+    // wide batches: one matrix-core launch per op (the members of a group only share their input)
+    for (int i = 0; i < n; ++i) {
+      const sqllm_op* op = &ops[i];
+      int rc = validate(op);
+      if (rc != SQLLM_OK) return rc;
+      if (op->vec != ops[0].vec || op->K != ops[0].K || op->bits != ops[0].bits || op->batch != ops[0].batch)
+        return SQLLM_E_GROUP;
+      if ((uint64_t)op->batch * (uint64_t)op->K >= (1ull << 31)) return SQLLM_E_SHAPE;  // 32-bit row offsets into vec
+      sqllm::LaunchArgs a;
+      a.ev_start = i == 0 ? e0 : nullptr;
+      a.ev_stop = i == n - 1 ? e1 : nullptr;
+      a.x = op->vec;
+      a.ga.n_seg = 1;
+      memset(a.ga.seg, 0, sizeof(a.ga.seg));
+      sqllm::Segment& sg = a.ga.seg[0];
+      sg.q = reinterpret_cast<const uint32_t*>(op->qweight);
+      sg.y = op->mul;
+      sg.lut = op->lookup_table;
+      sg.rows = op->rows;
+      sg.cols = op->cols;
+      sg.vals = op->vals;
+      sg.full_rows = op->full_rows;
+      sg.full_idx = op->full_row_indices;
+      make_plan_mfma(op, &sg.gm);
+      a.ga.block0[0] = 0;
+      for (int j = 1; j <= sqllm::kMaxSegments; ++j) a.ga.block0[j] = sg.gm.dense_block0 + sg.gm.dense_blocks;
+      rc = static_cast<int>(sqllm::launch_batched_mfma(op->bits, a, static_cast<hipStream_t>(stream)));
+      if (rc != SQLLM_OK) return rc;
+    }
+    return SQLLM_OK;
+  }
   sqllm_op tmp[sqllm::kMaxSegments];
   if (lin) {
     for (int i = 0; i < n; ++i) {

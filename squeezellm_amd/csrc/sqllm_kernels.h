@@ -88,6 +88,10 @@ struct LaunchArgs {
 // batch rows handled per weight pass for a given batch size (template instantiations 1/2/4/8)
 inline int batch_tile(int batch) { return batch <= 1 ? 1 : batch == 2 ? 2 : batch <= 4 ? 4 : 8; }
 
+// blocks of 16 batch rows one pass of the wide-batch (matrix-core) kernel covers: 1, 2 or 4
+inline int mfma_row_blocks(int batch) { return batch <= 16 ? 1 : batch <= 32 ? 2 : 4; }
+
 hipError_t launch_fused(int bits, const LaunchArgs& a, hipStream_t stream);
+hipError_t launch_batched_mfma(int bits, const LaunchArgs& a, hipStream_t stream);
 
 }  // namespace sqllm

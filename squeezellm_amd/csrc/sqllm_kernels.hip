@@ -1340,6 +1340,311 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide-batch dense role: fp32 MATRIX cores (the *_batched operators from `mfma_min_batch` rows up).
+//
+// The batch tiles above reuse one lookup for up to 8 vector FMAs, so a batched op costs VALU time
+// proportional to the batch (13B gate/up at batch 8: 2.8 x the batch-1 launch) and re-streams the
+// weights once per 8 rows.  Here the dequantised weights are the B operand of
+// v_mfma_f32_16x16x4_f32 (exact fp32: a plain fma chain; 32 cycles per SIMD, the fp32 vector rate):
+//     lane (c = l % 16, kq = l / 16)  loads the usual 16 bytes: 4 adjacent columns 4c .. 4c+3 of ITS
+//     qweight row r0 + kq (so one wave load is 4 rows x 64 columns, as in the other kernels) and
+//     supplies, in step s = 0..7 and column block j = 0..3,
+//         B = W[8 (r0 + kq) + s, col0 + 4c + j]     -- nibble s of its own word: no cross-lane traffic
+//         A = vec[m0 + 16 mb + c, 8 (r0 + kq) + s]  -- batch row c of row block mb, the same k
+//     and accumulates D[v] = mul[m0 + 16 mb + 4 kq + v, col0 + 4c + j].
+// (The matrix instruction only needs A and B to agree on WHICH four k's a step multiplies; taking
+// "nibble s of four consecutive rows" instead of four consecutive k's is what keeps every lane on
+// its own loaded word.)  3-bit: the same with 32-k units and four phases of 8 k's per unit.
+// A weight is looked up once however many batch rows there are; MB blocks of 16 rows (<= 64 rows
+// per pass) cost MB matrix instructions per step.  Budget per 4 rows x 64 columns of weights:
+// 44 VALU + 32 lookups against MB x 1024 matrix-pipe cycles -- the op is matrix-bound from the
+// first block on (~2.1 TB/s of 4-bit weights per 16 rows at a fully busy matrix pipe), so every
+// batch up to 16 costs the same.  Measured (13B gate/up shape, 5120 x 13824, 4-bit, MI355X):
+// 30 us for 1..16 rows with the matrix pipe 50 % busy (rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES: all
+// workgroups are resident at once and run their prologue / matrix / epilogue phases in step),
+// 47-51 TFLOP/s from 32 rows up -- against 38 us (8 rows), 74 us (16 rows) and 37 TFLOP/s for the
+// 8-row batch tiles; hence the default switch-over at 6 rows.
+// Batches beyond 64 rows put the next 64 rows in the next blockIdx.y: the weights of a workgroup's
+// slice (<= 256 KB) are then re-read from L2 / Infinity Cache, not from HBM.
+// vec reaches the A operands through a PRIVATE LDS tile per wave (the waves of a workgroup work on
+// different k's, so there is no barrier): 16 MB rows x 32 k's, written as 16-byte pieces by the lanes
+// that loaded them one chunk ahead, read back as two ds_read_b128 per row block.
+// Waves split the K slice, meet in LDS (fp32 adds) and leave as one atomic per (row, column).
+// The CSR and top-X roles are the ones of the other kernels, run over the pass's rows 8 at a time.
+// ------------------------------------------------------------------------------------------------
+constexpr int kXtStride = 36;  // floats per row of a wave's x tile (32 k's + 4: rows 4 apart in banks)
+constexpr int mfma_codebook_floats(int bits) { return bits == 4 ? 2 * 4096 / 4 : 4 * 8 * 128 / 4; }
+constexpr int mfma_lds_floats(int bits, int mb, int waves) {
+  // codebooks, then the waves' x tiles; the epilogue's slabs [waves][16][64] reuse the tile area
+  return cmax(mfma_codebook_floats(bits) + cmax(waves * 16 * mb * kXtStride, waves * 16 * 64), cmax(2 * kCsrSpanMax, kTopxLds));
+}
+
+template <int BITS, int MB, int WAVES>
+__device__ __forceinline__ void dense_role_mfma(const float* __restrict__ x, const u32x4* __restrict__ q,
+                                                float* __restrict__ y, const float* __restrict__ lut, int K, int N,
+                                                int batch, int m0, int bid, int n_col_tiles, int units_total,
+                                                int units_per_wg, float* lds) {
+  using F = Fmt<BITS>;
+  constexpr int L = F::kLut, R = F::kRows, KU = F::kK;
+  constexpr int NPH = KU / 8;          // phases of 8 k's per unit (4-bit: 1, 3-bit: 4)
+  constexpr int TR = 16 * MB;          // rows of the x tile
+  constexpr int XL = TR / 8;           // 16-byte pieces of vec a lane loads per phase
+  constexpr int ESTRIDE = (BITS == 4) ? 256 : 128;
+  constexpr int SUBB = (BITS == 4) ? (L * ESTRIDE) / 2 : L * ESTRIDE;
+  __builtin_amdgcn_s_waitcnt(0);  // clean slate for the compiler's wait-count model (see dense_role)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, grp = lane >> 4;
+  const int ct = bid % n_col_tiles;
+  const int ks = bid / n_col_tiles;
+  const int col0 = ct * kTileN;
+  // LDS: codebooks at address 0 in the layout of dense_role (conflict-free lookups), then the x tiles
+  // (one per wave); the epilogue's slabs live where the tiles were
+  constexpr int kCb = mfma_codebook_floats(BITS);
+  float* slabs = lds + kCb;
+  float* xt = lds + kCb + wave * (TR * kXtStride);
+
+  // ---- codebook loads (staged row-wise exactly as in dense_role) ----
+  constexpr int EPW = 32 / WAVES, RPW = 16 / WAVES;
+  constexpr int NE = (BITS == 4) ? EPW : RPW;
+  float ev[NE];
+  const int st_j = (BITS == 4) ? 2 * (wave & 1) + (lane >> 5) : (wave & 3);
+  const int st_h = (BITS == 4) ? (wave >> 1) : (wave >> 2);
+  {
+    int c = col0 + 4 * i16 + st_j;
+    if (c > N - 1) c = N - 1;
+    const float* src = lut + (size_t)c * L;
+    if constexpr (BITS == 4) {
+#pragma unroll
+      for (int i = 0; i < EPW / 4; ++i) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + st_h * EPW + 4 * i);
+        ev[4 * i] = t.x; ev[4 * i + 1] = t.y; ev[4 * i + 2] = t.z; ev[4 * i + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) ev[i] = src[2 * (st_h * RPW + i) + (lane >> 5)];
+    }
+  }
+  // ---- this workgroup's K range; a wave's group g = units u_beg + 4 (wave + WAVES g) + grp ----
+  const int u_beg = ks * units_per_wg;
+  int u_end = u_beg + units_per_wg;
+  if (u_end > units_total) u_end = units_total;
+  const int n_groups_wg = (u_end - u_beg + 3) / 4;
+  const int n_g = n_groups_wg > wave ? (n_groups_wg - wave + WAVES - 1) / WAVES : 0;
+  const int row_stride = N / 4;  // in 16-byte units
+  int cidx = col0 / 4 + i16;
+  if (cidx > row_stride - 1) cidx = row_stride - 1;
+  const char* qbase = reinterpret_cast<const char*>(q);
+  const uint32_t lane_bytes = 16u * (uint32_t)cidx;
+  const uint32_t row_bytes = 16u * (uint32_t)row_stride;
+  // vec pieces: lane -> (tile row l / 8 + 8 j, lane row piece >> 1 of the group, half piece & 1)
+  int xrow[XL];
+#pragma unroll
+  for (int j = 0; j < XL; ++j) {
+    int r = m0 + (lane >> 3) + 8 * j;
+    if (r > batch - 1) r = batch - 1;  // rows past the batch re-read its last row; never stored
+    xrow[j] = r * K + 4 * (lane & 1);
+  }
+  const int xkq = (lane >> 1) & 3;  // which lane row's k's this lane's pieces belong to
+  auto group_unit = [&](int g, int kq) {  // unit of lane row kq in this wave's group g (may be >= u_end)
+    return u_beg + 4 * (wave + WAVES * g) + kq;
+  };
+  auto load_w = [&](int g, u32x4 (&dw)[R]) {
+    int u = group_unit(g, grp);
+    if (u > u_end - 1) u = u_end - 1;  // clamped re-read inside the slice; its x pieces are zeroed
+    if (u < u_beg) u = u_beg;
+    const uint32_t off = (uint32_t)(u * R) * row_bytes + lane_bytes;
+#pragma unroll
+    for (int r = 0; r < R; ++r) dw[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(qbase + (off + r * row_bytes)));
+  };
+  // (the pieces of a unit past the slice are zeroed where they are PARKED, not here: a select right
+  // behind the load would make the wave wait for it on the spot)
+  auto load_x = [&](int g, int ph, f32x4 (&dx)[XL]) {
+    int u = group_unit(g, xkq);
+    if (u > u_end - 1) u = u_end - 1;
+    if (u < u_beg) u = u_beg;
+#pragma unroll
+    for (int j = 0; j < XL; ++j) dx[j] = *reinterpret_cast<const f32x4*>(x + xrow[j] + u * KU + 8 * ph);
+  };
+  u32x4 wa[R], wb[R];
+  f32x4 xa[XL], xb[XL];
+  load_w(0, wa);
+  load_x(0, 0, xa);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- stage the codebooks ----
+  if constexpr (BITS == 4) {
+    float* dst = lds + ((wave & 1) * 4096 + st_h * EPW * ESTRIDE) / 4 + lane;
+#pragma unroll
+    for (int i = 0; i < EPW; ++i) dst[i * (ESTRIDE / 4)] = ev[i];
+  } else {
+    float* dst = lds + (st_j * SUBB) / 4 + (lane >> 5) * (ESTRIDE / 4) + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) dst[2 * (st_h * RPW + i) * (ESTRIDE / 4)] = ev[i];
+  }
+  f32x4 acc[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t lane_off = 4 * (i16 + 16 * (grp & 1));
+  uint32_t tb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) tb[j] = j * SUBB + 4 * (i16 + 16 * (grp & 1));
+  float* xt_w = xt + (lane >> 3) * kXtStride + 8 * xkq + 4 * (lane & 1);  // where this lane parks its pieces
+  const float* xt_r = xt + i16 * kXtStride + 8 * grp;                     // batch row i16 of block 0, this lane row's 8 k's
+  __syncthreads();  // codebooks staged, sums zeroed
+
+  // one phase: 8 k's of each lane row against all MB row blocks; v[j][s] = weight s of column 4c + j
+  auto phase = [&](const float (&v)[4][8], const f32x4 (&dx)[XL], int g) {
+    const bool live = group_unit(g, xkq) < u_end;
+#pragma unroll
+    for (int j = 0; j < XL; ++j) *reinterpret_cast<f32x4*>(xt_w + 8 * j * kXtStride) = live ? dx[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 alo[MB], ahi[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      alo[mb] = *reinterpret_cast<const f32x4*>(xt_r + 16 * mb * kXtStride);
+      ahi[mb] = *reinterpret_cast<const f32x4*>(xt_r + 16 * mb * kXtStride + 4);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const float a = s2 < 4 ? alo[mb][s2 & 3] : ahi[mb][s2 & 3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v[j][s2], acc[mb][j], 0, 0, 0);
+      }
+  };
+  auto lookups = [&](const u32x4 (&t)[R], auto ph_tag, float (&v)[4][8]) {
+    constexpr int PH = decltype(ph_tag)::value;
+    if constexpr (BITS == 4) {
+      const uint32_t w4[4] = {t[0].x, t[0].y, t[0].z, t[0].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t lo = w4[j] & 0x0F0F0F0Fu, hi = (w4[j] >> 4) & 0x0F0F0F0Fu;
+        const int off = (j >> 1) * 4096 + (j & 1) * 128;
+        v[j][0] = lds_read_f32(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0400u) + off);
+        v[j][1] = lds_read_f32(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0400u) + off);
+        v[j][2] = lds_read_f32(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0500u) + off);
+        v[j][3] = lds_read_f32(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0500u) + off);
+        v[j][4] = lds_read_f32(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0600u) + off);
+        v[j][5] = lds_read_f32(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0600u) + off);
+        v[j][6] = lds_read_f32(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0700u) + off);
+        v[j][7] = lds_read_f32(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0700u) + off);
+      }
+    } else {
+      const uint32_t t0[4] = {t[0].x, t[0].y, t[0].z, t[0].w};
+      const uint32_t t1[4] = {t[1].x, t[1].y, t[1].z, t[1].w};
+      const uint32_t t2[4] = {t[2].x, t[2].y, t[2].z, t[2].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j][0] = lds_read_f32(tb[j] | field3_x128<8 * PH + 0>(t0[j], t1[j], t2[j]));
+        v[j][1] = lds_read_f32(tb[j] | field3_x128<8 * PH + 1>(t0[j], t1[j], t2[j]));
+        v[j][2] = lds_read_f32(tb[j] | field3_x128<8 * PH + 2>(t0[j], t1[j], t2[j]));
+        v[j][3] = lds_read_f32(tb[j] | field3_x128<8 * PH + 3>(t0[j], t1[j], t2[j]));
+        v[j][4] = lds_read_f32(tb[j] | field3_x128<8 * PH + 4>(t0[j], t1[j], t2[j]));
+        v[j][5] = lds_read_f32(tb[j] | field3_x128<8 * PH + 5>(t0[j], t1[j], t2[j]));
+        v[j][6] = lds_read_f32(tb[j] | field3_x128<8 * PH + 6>(t0[j], t1[j], t2[j]));
+        v[j][7] = lds_read_f32(tb[j] | field3_x128<8 * PH + 7>(t0[j], t1[j], t2[j]));
+      }
+    }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  using P3 = std::integral_constant<int, 3>;
+  // decode group g out of (w, xcur = its phase-0 vec pieces); later phases' pieces are loaded one
+  // phase ahead, the NEXT group's weights and phase-0 pieces (into wn / xn) before the first phase
+  auto decode_group = [&](int g, const u32x4 (&w)[R], f32x4 (&xcur)[XL], u32x4 (&wn)[R], f32x4 (&xn)[XL]) {
+    load_w(g + 1, wn);
+    float v[4][8];
+    if constexpr (NPH == 1) {
+      load_x(g + 1, 0, xn);
+      __builtin_amdgcn_sched_barrier(0);
+      lookups(w, P0{}, v);
+      phase(v, xcur, g);
+    } else {
+      f32x4 xo[XL];
+      load_x(g, 1, xo);
+      __builtin_amdgcn_sched_barrier(0);
+      lookups(w, P0{}, v);
+      phase(v, xcur, g);
+      load_x(g, 2, xcur);
+      __builtin_amdgcn_sched_barrier(0);
+      lookups(w, P1{}, v);
+      phase(v, xo, g);
+      load_x(g, 3, xo);
+      __builtin_amdgcn_sched_barrier(0);
+      lookups(w, P2{}, v);
+      phase(v, xcur, g);
+      load_x(g + 1, 0, xn);
+      __builtin_amdgcn_sched_barrier(0);
+      lookups(w, P3{}, v);
+      phase(v, xo, g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // two register sets swap roles (a copy would make the compiler wait for the loads in flight);
+  // groups past the wave's last one re-read valid memory and multiply by zeroed vec pieces
+  for (int g = 0; g < n_g; g += 2) {
+    decode_group(g, wa, xa, wb, xb);
+    decode_group(g + 1, wb, xb, wa, xa);
+  }
+
+  // ---- waves meet in LDS, one row block at a time: every wave parks its 16 x 64 partial sums in its
+  // slab (plain 16-byte stores: LDS float atomics execute lane by lane -- 16 of them per wave cost
+  // 50 us per launch here), the workgroup sums the slabs and issues one atomic per (row, column) ----
+  __syncthreads();  // everybody is done with the x tiles
+  float* slab = slabs + wave * (16 * 64) + (4 * grp) * 64 + 4 * i16;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    if (mb) __syncthreads();
+    *reinterpret_cast<f32x4*>(slab + 0 * 64) = f32x4{acc[mb][0].x, acc[mb][1].x, acc[mb][2].x, acc[mb][3].x};
+    *reinterpret_cast<f32x4*>(slab + 1 * 64) = f32x4{acc[mb][0].y, acc[mb][1].y, acc[mb][2].y, acc[mb][3].y};
+    *reinterpret_cast<f32x4*>(slab + 2 * 64) = f32x4{acc[mb][0].z, acc[mb][1].z, acc[mb][2].z, acc[mb][3].z};
+    *reinterpret_cast<f32x4*>(slab + 3 * 64) = f32x4{acc[mb][0].w, acc[mb][1].w, acc[mb][2].w, acc[mb][3].w};
+    __syncthreads();
+#pragma unroll
+    for (int e = tid; e < 16 * 64; e += WAVES * 64) {
+      const int r = m0 + 16 * mb + (e >> 6);
+      const int col = col0 + (e & 63);
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) sum += slabs[w * (16 * 64) + e];
+      if (r < batch && col < N) acc_add(y + (size_t)r * N + col, sum);
+    }
+  }
+}
+
+template <int BITS, int MB, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+sqllm_fused_batched(const float* x, const GroupArgs ga) {
+  constexpr int T = WAVES * 64;
+  __shared__ __attribute__((aligned(16))) float lds[mfma_lds_floats(BITS, MB, WAVES)];
+  const Segment& sg = ga.seg[0];
+  const KernelGeom& gm = sg.gm;
+  const int bid = blockIdx.x;
+  const int m0 = blockIdx.y * 16 * MB;
+  int rows_here = gm.batch - m0;
+  if (rows_here > 16 * MB) rows_here = 16 * MB;
+  const int d = bid - gm.dense_block0;
+  const int sp = bid < gm.dense_block0 ? bid : -1;
+  if (d >= 0 && d < gm.dense_blocks) {
+    dense_role_mfma<BITS, MB, WAVES>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, d,
+                                     gm.col_tiles, gm.units_total, gm.units_per_wg, lds);
+  } else if (sp >= 0 && sp < gm.csr_blocks) {
+    for (int bb = 0; bb < rows_here; bb += kMaxBatchTile) {
+      if (bb) __syncthreads();
+      csr_role<T, kMaxBatchTile, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, m0 + bb,
+                                               rows_here - bb < kMaxBatchTile ? rows_here - bb : kMaxBatchTile, sp, lds, nullptr, 0);
+    }
+  } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
+    topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, m0, rows_here, sp - gm.csr_blocks, lds);
+  }
+}
+
 #ifdef SQLLM_ABLATION_BUILD
 // calibration kernels (measurement builds only): what does this box give an empty launch and a
 // plain linear 16-B/lane streaming read of the same bytes?
@@ -1446,6 +1751,31 @@ static hipError_t launch_bt(const LaunchArgs& a, hipStream_t stream) {
     case 4: return launch_inst<BITS, 4, kWaves, 0, LIN>(a, stream);
     default: return launch_inst<BITS, 8, kWaves, 0, LIN>(a, stream);
   }
+}
+
+template <int BITS, int MB>
+static hipError_t launch_mfma_inst(const LaunchArgs& a, hipStream_t stream) {
+  const KernelGeom& gm = a.ga.seg[0].gm;
+  dim3 grid(gm.dense_block0 + gm.dense_blocks, (gm.batch + 16 * MB - 1) / (16 * MB));
+  auto kern = sqllm_fused_batched<BITS, MB, kWaves>;
+  const float* x = static_cast<const float*>(a.x);
+  if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga);
+  else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga);
+  return hipGetLastError();
+}
+
+template <int BITS>
+static hipError_t launch_mfma_bits(const LaunchArgs& a, hipStream_t stream) {
+  switch (mfma_row_blocks(a.ga.seg[0].gm.batch)) {
+    case 1: return launch_mfma_inst<BITS, 1>(a, stream);
+    case 2: return launch_mfma_inst<BITS, 2>(a, stream);
+    default: return launch_mfma_inst<BITS, 4>(a, stream);
+  }
+}
+
+// one op (a.ga.seg[0]), operator ABI, batch rows through the matrix cores
+hipError_t launch_batched_mfma(int bits, const LaunchArgs& a, hipStream_t stream) {
+  return bits == 4 ? launch_mfma_bits<4>(a, stream) : launch_mfma_bits<3>(a, stream);
 }
 
 hipError_t launch_fused(int bits, const LaunchArgs& a, hipStream_t stream) {

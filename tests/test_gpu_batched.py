@@ -1,0 +1,139 @@
+"""GPU parity of the *_batched operators beyond the 8-row batch tiles: the matrix-core kernel
+(batches of `mfma_min_batch` = 6 rows and more), at the batch sizes the reference's callers use --
+PPL evaluation runs the batched ops with B = 2048 (/root/reference/llama.py:91-103 ->
+squeezellm/quant.py:313-383) -- and at the BASELINE.json configurations that name a batch:
+config 1 (OPT-1.3B shapes with bias, batch 1 x seq 128 -> B = 128) and config 4 (LLaMA-13B shapes,
+0.45 % sparse + top-10, batch 1..8 and beyond).  Same tolerances as tests/test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL_FP64 = 2e-5
+
+
+@pytest.fixture(scope="module")
+def qc():
+    from squeezellm_amd import quant_cuda
+
+    return quant_cuda
+
+
+def run_batched(qc, gpu, case, kind, batch, seed=1):
+    import torch
+
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=(batch, case["K"])).astype(np.float16).astype(np.float32)
+    mul = rng.normal(0, 0.5, size=(batch, case["N"])).astype(np.float32)
+    t = H.to_torch(case, gpu)
+    yt = torch.from_numpy(mul).to(gpu)
+    H.call_op(qc, t, torch.from_numpy(x).to(gpu), yt, kind, True)
+    torch.cuda.synchronize()
+    return x, mul, yt.cpu().numpy()
+
+
+@pytest.mark.parametrize("bits,K,N", [(4, 256, 192), (3, 96 * 2, 260), (4, 1024, 132), (3, 1024, 776), (4, 32, 4), (3, 32, 8)])
+@pytest.mark.parametrize("kind", ["dense", "spmv", "hybrid"])
+@pytest.mark.parametrize("batch", [6, 16, 17, 33, 64, 65, 130])
+def test_wide_batches_vs_oracle(qc, gpu, bits, K, N, kind, batch):
+    """One, two and four row blocks of 16, several passes of 64 rows, ragged ends in every dimension
+    (N not a multiple of the 64-column tile, K = 32: a single unit, fewer units than lane rows)."""
+    case = H.make_case(bits, K, N, sparse=0.03 if kind != "dense" else 0, topX=3 if kind == "hybrid" else 0,
+                       heavy_rows=1 if kind != "dense" and N >= 8 else 0, seed=bits * 1000 + K + N)
+    x, mul, got = run_batched(qc, gpu, case, kind, batch)
+    assert H.rel_err(got, H.oracle_ref(case, x, mul, kind)) <= TOL_FP64
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+def test_ppl_eval_batch_2048(qc, gpu, bits):
+    """B = 2048, the batch the reference's perplexity evaluation feeds the batched ops."""
+    case = H.make_case(bits, 512, 320, sparse=0.01, topX=4, heavy_rows=2, seed=77)
+    x, mul, got = run_batched(qc, gpu, case, "hybrid", 2048)
+    assert H.rel_err(got, H.oracle_ref(case, x, mul, "hybrid")) <= TOL_FP64
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+def test_both_batched_paths_agree(qc, gpu, bits):
+    """The 8-row batch tiles and the matrix-core kernel are two implementations of one operator."""
+    import torch
+
+    from squeezellm_amd import _lib
+
+    case = H.make_case(bits, 2048, 1024, sparse=0.0045, topX=10, heavy_rows=4, seed=5)
+    t = H.to_torch(case, gpu)
+    x = torch.randn((24, 2048), device=gpu)
+    outs = []
+    try:
+        for min_batch in (1 << 30, 1):
+            _lib.set_option("mfma_min_batch", min_batch)
+            y = torch.zeros((24, 1024), device=gpu)
+            H.call_op(qc, t, x, y, "hybrid", True)
+            torch.cuda.synchronize()
+            outs.append(y.cpu().numpy())
+    finally:
+        _lib.set_option("mfma_min_batch", 6)
+    assert H.rel_err(outs[1], outs[0]) <= 1e-5
+
+
+LLAMA13B = [(5120, 5120), (5120, 13824), (13824, 5120)]
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("K,N", LLAMA13B)
+@pytest.mark.parametrize("batch", [2, 8, 16])
+def test_llama13b_shapes_batched_hybrid(qc, gpu, bits, K, N, batch):
+    """BASELINE config 4 at full size on all three 13B shapes, against the C oracle (batch 2: batch
+    tiles; 8 and 16: matrix cores)."""
+    case = H.make_case(bits, K, N, sparse=0.0045, topX=10, heavy_rows=10, seed=13)
+    x, mul, got = run_batched(qc, gpu, case, "hybrid", batch)
+    ref = H.c_matvec(H.c_oracle(), case, x, mul, batched=True)
+    assert H.rel_err(got, ref) <= TOL_FP64
+
+
+OPT13 = [(2048, 2048), (2048, 8192), (8192, 2048)]
+
+
+@pytest.mark.parametrize("K,N", OPT13)
+def test_opt13b_config1_batch128_with_bias(gpu, K, N):
+    """BASELINE config 1: OPT-1.3B w4 dense-only, batch 1 x seq 128 -> the batched branch of
+    QuantLinearLUT.forward with B = 128 and a bias added AFTER the cast back to the input dtype
+    (squeezellm/quant.py:313-321, :380-383; shapes and bias: models/opt-1.3b/config.json)."""
+    import torch
+
+    from squeezellm_amd import quant
+
+    case = H.make_case(4, K, N, seed=K + N)
+    rng = np.random.default_rng(3)
+    case["bias"] = rng.normal(0, 0.01, N).astype(np.float32)
+    mod = quant.QuantLinearLUT.from_operands(H.to_torch(case, gpu))
+    x = rng.normal(size=(1, 128, K)).astype(np.float16)
+    y = mod(torch.from_numpy(x).to(gpu))
+    torch.cuda.synchronize()
+    ref = H.oracle.quantlinear_forward(x, case)
+    assert y.shape == (1, 128, N) and y.dtype == torch.float16
+    # fp16 output: one rounding of the fp32 result, one of the bias add
+    assert H.rel_err(y.float().cpu().numpy(), ref.astype(np.float32)) <= 2e-3
+
+
+LLAMA65B = [(8192, 8192), (8192, 22016), (22016, 8192)]
+
+
+@pytest.mark.parametrize("K,N", LLAMA65B)
+def test_llama65b_shapes_vs_c_oracle(qc, gpu, K, N):
+    """BASELINE config 5 (single-GPU leg of the sharded model): the three 65B shapes, w3 + 0.45 %
+    sparse + top-10, batch-1 hybrid op against the C oracle."""
+    import torch
+
+    case = H.make_case(3, K, N, sparse=0.0045, topX=10, heavy_rows=10, seed=65)
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=K).astype(np.float16).astype(np.float32)
+    mul = rng.normal(0, 0.5, N).astype(np.float32)
+    t = H.to_torch(case, gpu)
+    yt = torch.from_numpy(mul).to(gpu)
+    H.call_op(qc, t, torch.from_numpy(x).to(gpu), yt, "hybrid", False)
+    torch.cuda.synchronize()
+    ref = H.c_matvec(H.c_oracle(), case, x, mul, batched=False)
+    assert H.rel_err(yt.cpu().numpy(), ref) <= TOL_FP64

@@ -24,16 +24,17 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 enum Kind { K_PERM = 0, K_FMA, K_FMAC_SGPR, K_PKFMA, K_PKFMA_SGPR, K_ANDOR, K_FMAC_DPP, K_LDS32, K_LDS64, K_LDS128,
-            K_MIX4, K_MIX4_FMA, K_MIX3, K_LDSW64, K_LDSW2x32, K_OVL_B64, K_OVL_B32, K_N };
+            K_MIX4, K_MIX4_FMA, K_MIX3, K_LDSW64, K_LDSW2x32, K_OVL_B64, K_OVL_B32, K_MFMA16, K_MFMA4, K_MFMA32, K_N };
 static const char* kNames[K_N] = {
     "v_perm_b32", "v_fma_f32 (vgpr)", "v_fmac_f32 (sgpr x)", "v_pk_fma_f32 (vgpr)", "v_pk_fma_f32 (sgpr pair x)",
     "v_and_or_b32", "v_fmac_f32 dpp row_newbcast", "ds_read_b32", "ds_read_b64", "ds_read_b128",
     "mix w4 pair: 1 perm + 1 ds_read_b64 + 1 pk_fma(sgpr)", "mix w4 pair: 1 perm + 1 ds_read_b64 + 2 fmac(sgpr)",
     "mix w3 pair: 2 valu addr + 1 ds_read_b64 + 1 pk_fma(sgpr)", "ds_write_b64", "ds_write2_b32",
-    "overlap: 64 v_perm + 32 ds_read_b64 (independent, one wait per block)", "overlap: 64 v_perm + 32 ds_read_b32 (independent, one wait per block)"};
+    "overlap: 64 v_perm + 32 ds_read_b64 (independent, one wait per block)", "overlap: 64 v_perm + 32 ds_read_b32 (independent, one wait per block)",
+    "v_mfma_f32_16x16x4_f32 (4 independent accumulators)", "v_mfma_f32_4x4x1_16b_f32 (4 independent accumulators)", "v_mfma_f32_32x32x2_f32 (2 independent accumulators)"};
 // instructions per block (per loop iteration), and which of them are VALU / LDS
-static const int kValuPerBlock[K_N] = {64, 64, 64, 64, 64, 64, 64, 0, 0, 0, 32, 48, 48, 0, 0, 64, 64};
-static const int kLdsPerBlock[K_N] = {0, 0, 0, 0, 0, 0, 0, 64, 64, 64, 16, 16, 16, 64, 64, 32, 32};
+static const int kValuPerBlock[K_N] = {64, 64, 64, 64, 64, 64, 64, 0, 0, 0, 32, 48, 48, 0, 0, 64, 64, 32, 32, 16};
+static const int kLdsPerBlock[K_N] = {0, 0, 0, 0, 0, 0, 0, 64, 64, 64, 16, 16, 16, 64, 64, 32, 32, 0, 0, 0};
 
 #define REP2(x) x x
 #define REP4(x) REP2(x) REP2(x)
@@ -61,6 +62,12 @@ __global__ void __launch_bounds__(1024) k_rate(unsigned long long* out, int iter
   const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sx)));
   const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sx * 2.f)));
   const f32x2 spair = {s0, s1};
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  f32x4 mc0 = {f0, f1, f2, f3}, mc1 = {f4, f5, f6, f7}, mc2 = {f1, f2, f3, f4}, mc3 = {f5, f6, f7, f0};
+  f32x16 md0, md1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { md0[e] = f0 + e; md1[e] = f1 - e; }
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   for (int it = 0; it < iters; ++it) {
@@ -141,6 +148,15 @@ __global__ void __launch_bounds__(1024) k_rate(unsigned long long* out, int iter
                         "v_perm_b32 %4, %4, %8, %9\n ds_read_b32 %12, %8 offset:1536\n v_perm_b32 %5, %5, %8, %9\n v_perm_b32 %6, %6, %8, %9\n ds_read_b32 %13, %8 offset:3584\n v_perm_b32 %7, %7, %8, %9\n")
                    "s_waitcnt lgkmcnt(0)\n"
                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(base32), "s"(sel), "v"(f0), "v"(f1), "v"(f2), "v"(f3) : "memory");
+    } else if constexpr (KIND == K_MFMA16) {
+      asm volatile(REP8("v_mfma_f32_16x16x4_f32 %0, %4, %5, %0\n v_mfma_f32_16x16x4_f32 %1, %4, %6, %1\n v_mfma_f32_16x16x4_f32 %2, %4, %7, %2\n v_mfma_f32_16x16x4_f32 %3, %4, %8, %3\n")
+                   : "+v"(mc0), "+v"(mc1), "+v"(mc2), "+v"(mc3) : "v"(m), "v"(f0), "v"(f1), "v"(f2), "v"(f3));
+    } else if constexpr (KIND == K_MFMA4) {
+      asm volatile(REP8("v_mfma_f32_4x4x1_16b_f32 %0, %4, %5, %0\n v_mfma_f32_4x4x1_16b_f32 %1, %4, %6, %1\n v_mfma_f32_4x4x1_16b_f32 %2, %4, %7, %2\n v_mfma_f32_4x4x1_16b_f32 %3, %4, %8, %3\n")
+                   : "+v"(mc0), "+v"(mc1), "+v"(mc2), "+v"(mc3) : "v"(m), "v"(f0), "v"(f1), "v"(f2), "v"(f3));
+    } else if constexpr (KIND == K_MFMA32) {
+      asm volatile(REP8("v_mfma_f32_32x32x2_f32 %0, %2, %3, %0\n v_mfma_f32_32x32x2_f32 %1, %2, %4, %1\n")
+                   : "+v"(md0), "+v"(md1) : "v"(m), "v"(f0), "v"(f1));
     } else if constexpr (KIND == K_MIX3) {
       asm volatile(REP4(
                        "v_lshrrev_b32 %8, 3, %4\n v_and_or_b32 %8, %8, %7, %6\n ds_read_b64 %0, %8\n v_lshrrev_b32 %9, 9, %5\n v_and_or_b32 %9, %9, %7, %6\n ds_read_b64 %1, %9\n"
@@ -154,7 +170,7 @@ __global__ void __launch_bounds__(1024) k_rate(unsigned long long* out, int iter
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   // keep everything alive
-  float keep = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + p0.x + p1.y + p2.x + p3.y + q0.x + q1.x + q2.x + q3.x;
+  float keep = mc0.x + mc1.y + mc2.z + mc3.w + md0[3] + md1[9] + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + p0.x + p1.y + p2.x + p3.y + q0.x + q1.x + q2.x + q3.x;
   unsigned keepu = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
   if (keep == 1234.5678f && keepu == 77u) lds[tid] = keep;
   if (lane == 0) out[blockIdx.x * 16 + (tid >> 6)] = t1 - t0;
@@ -186,7 +202,7 @@ static void run(unsigned long long* dout, int cus) {
     cyc /= waves;
     const double nv = (double)kValuPerBlock[KIND] * iters, nl = (double)kLdsPerBlock[KIND] * iters;
     printf("%-56s waves/SIMD=%d  wave cycles %9.0f  ", kNames[KIND], wps, cyc);
-    if (nv > 0) printf("cyc per VALU inst per SIMD %.2f  ", cyc / (nv * wps));
+    if (nv > 0) printf("cyc per %s inst per SIMD %.2f  ", KIND >= K_MFMA16 ? "MFMA" : "VALU", cyc / (nv * wps));
     if (nl > 0) printf("cyc per LDS inst per CU %.2f  ", cyc / (nl * wps * 4));
     printf("(kernel %.1f us, clock ~%.2f GHz)\n", ms * 1e3, cyc / (ms * 1e3) / 1e3);
   }
@@ -215,5 +231,8 @@ int main() {
   run<K_MIX3>(dout, cus);
   run<K_OVL_B64>(dout, cus);
   run<K_OVL_B32>(dout, cus);
+  run<K_MFMA16>(dout, cus);
+  run<K_MFMA4>(dout, cus);
+  run<K_MFMA32>(dout, cus);
   return 0;
 }
