@@ -10,12 +10,19 @@ libsqllm_hip.so and replayed as a HIP graph.  Inputs are resident in HBM before 
 `value` = tokens/s of the whole job = steps / wall time (barrier + synchronize on both sides, MAX
 over ranks), attention / norms / lm_head excluded exactly as in BASELINE.md section 2.
 
-Legs after the timed region (rank 0 of a 1-GPU run only):
-  * roofline     every kernel dispatch of one pass bracketed by its own HIP start/stop events
-                 (sqllm_profile_sequence): achieved = algorithmic bytes per launch / average kernel
-                 duration, against the 8 TB/s HBM peak;
-  * cpu_baseline the C port of the same algorithm (oracle/sqllm_oracle.c, OpenMP) timed on the
-                 host cores over a bounded sample of the same workload.
+The ONE JSON line answers every number BASELINE.json's metric asks for:
+  * the headline fields: config 7b-w4-s0 (BASELINE.json configs[1]), timed for exactly --steps
+    steps; the same block is repeated (--repeats, default 5) and the median / min are reported too;
+  * `roofline`      every kernel dispatch of one pass bracketed by its own HIP start/stop events
+                    (sqllm_profile_groups): achieved = algorithmic bytes per launch / average
+                    kernel duration, against the 8 TB/s HBM peak; `per_layer_us` = the per-shape
+                    kernel microseconds;
+  * `sub_records`   (1-GPU default run) the other halves of the metric, measured the same way in
+                    the same process: 7b-w4-s45 and 7b-w3-s45 (tokens/s, ms, roofline, per-shape
+                    microseconds) and the 13B batch-{1,2,4,8} leg of configs[3] on the 13B shapes;
+  * `cpu_baseline`  the reference-style CPU path on the host cores: torch dequant (codebook gather)
+                    + torch.matmul, torch.matmul alone on pre-dequantised weights, and the OpenMP C
+                    port of the kernels' algorithm, each on a bounded sample of the same workload.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, backend nccl = RCCL), two modes:
   * replicas (default when the model fits one GPU, i.e. every config but 65B): the unit of work is
@@ -31,6 +38,7 @@ import argparse
 import ctypes
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -51,6 +59,8 @@ CONFIGS = {
     "13b-w4-s45": dict(model="llama-13b", bits=4, sparse=0.0045, topX=10, op="vecquant4matmul_spmv_hybrid_nuq_perchannel"),
     "65b-w3-s45": dict(model="llama-65b", bits=3, sparse=0.0045, topX=10, op="vecquant3matmul_spmv_hybrid_nuq_perchannel"),
 }
+SUB_RECORD_CONFIGS = ("7b-w4-s45", "7b-w3-s45")  # the s45 halves of the metric
+SHARED_INPUT = {"k_proj": "q_proj", "v_proj": "q_proj", "up_proj": "gate_proj"}
 
 
 def parse_args():
@@ -58,6 +68,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5, help="blocks of --steps steps timed for the median / min (the first is the contract's)")
     ap.add_argument("--config", default="7b-w4-s0", choices=sorted(CONFIGS))
     ap.add_argument("--layers", type=int, default=None, help="decoder layers to build (default: the model's)")
     ap.add_argument("--launch", default="graph", choices=["graph", "sequence"],
@@ -69,17 +80,152 @@ def parse_args():
                     help="N > 1: independent replicas (weak scaling) or layer-sharded ring pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-sub-records", action="store_true", help="skip the s45 / 13B-batch sub-records of the default run")
     ap.add_argument("--per-shape", action="store_true", help="print the per-shape kernel table to stderr")
     return ap.parse_args()
 
 
-def cpu_baseline(layers, model_layers: int, budget_s: float = 12.0):
-    """Time the C port (oracle/libsqllm_oracle.so, OpenMP over the host cores) on decoder layers of
-    the same workload until ~budget_s of CPU time is spent; scale to a whole pass."""
+# ---------------------------------------------------------------------------------------------------
+# workload construction
+# ---------------------------------------------------------------------------------------------------
+def build_layers(cfg, dev, lo, hi):
+    from squeezellm_amd import synth
+
+    spec = synth.MODEL_SHAPES[cfg["model"]]
+    per_layer = len(spec["linears"])
+    layers = []
+    for li in range(lo, hi):
+        for j, (lname, K, N) in enumerate(spec["linears"]):
+            lay = synth.make_layer(K, N, cfg["bits"], sparse_frac=cfg["sparse"], topX=cfg["topX"],
+                                   heavy_rows=10 if cfg["sparse"] > 0 else 0, device=dev, seed=li * per_layer + j)
+            lay["name"] = f"layers.{li}.{lname}"
+            layers.append(lay)
+    return layers
+
+
+def decoder_inputs(layers, dev, gen, batch=0):
+    """Activations as in the decoder layer: q/k/v read the same hidden state, gate/up the same
+    post-attention state, o_proj and down_proj their own inputs (model_parse.py:53-61)."""
+    import torch
+
+    xs, last = [], {}
+    for l in layers:
+        lname = l["name"].rsplit(".", 1)[1]
+        src = SHARED_INPUT.get(lname)
+        if src is not None and src in last:
+            xs.append(last[src])
+        else:
+            shape = (batch, l["K"]) if batch else (l["K"],)
+            xs.append(torch.randn(shape, device=dev, generator=gen, dtype=torch.float16).float())
+        last[lname] = xs[-1]
+    ys = [torch.zeros((batch, l["N"]) if batch else (l["N"],), device=dev, dtype=torch.float32) for l in layers]
+    return xs, ys
+
+
+def per_shape_table(seq, layers, bytes_per_op, us):
     import numpy as np
 
-    path = os.path.join(ROOT, "oracle", "libsqllm_oracle.so")
-    lib = ctypes.CDLL(path)
+    table = {}
+    for grp, u in zip(seq.groups, us):
+        key = "+".join(f"{layers[i]['K']}x{layers[i]['N']}" for i in grp)
+        table.setdefault(key, []).append((u, sum(bytes_per_op[i] for i in grp)))
+    out = {}
+    for key, lst in table.items():
+        u = np.array([a for a, _ in lst])
+        b = lst[0][1]
+        out[key] = {"us_mean": round(float(u.mean()), 3), "us_min": round(float(u.min()), 3), "MB": round(b / 1e6, 3),
+                    "GBps": round(b / (u.mean() * 1e-6) / 1e9, 1), "hbm_frac": round(b / (u.mean() * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def roofline_leg(seq, layers, bytes_per_op, cfg, config_name, fused):
+    """achieved = algorithmic bytes per launch / mean kernel duration, each dispatch bracketed by its own
+    HIP events on the launch stream (sqllm_profile_groups)."""
+    pass_bytes = float(sum(bytes_per_op))
+    seq.profile(reps=1)  # warm
+    us = seq.profile(reps=5)  # one entry per launch (= per group of fused linears)
+    avg_us = float(us.mean())
+    n_launch = seq.n_groups
+    achieved = pass_bytes / n_launch / (avg_us * 1e-6) / 1e9
+    traffic, source = pmc_traffic_per_launch(config_name, fused)
+    roof = {
+        "bound": "hbm",
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        # HBM bytes per launch from the PMC counters.  They cannot be read live (rocprofv3 --pmc runs,
+        # one counter group per pass), so this is the COMMITTED summary of those passes over this very
+        # command (tools/collect_profiles.sh), gfx950 correction applied (FETCH_SIZE x 2); null if none
+        "traffic": traffic,
+        "traffic_source": source,
+        "kernel": f"sqllm_fused_matvec<{cfg['bits']},1>",
+        "avg_kernel_us": round(avg_us, 3),
+        "launches_per_step": n_launch,
+        "algorithmic_bytes_per_launch": int(pass_bytes / n_launch),
+        "sum_kernel_ms_per_step": round(float(us.sum()) * 1e-3, 4),
+    }
+    return roof, per_shape_table(seq, layers, bytes_per_op, us)
+
+
+def pmc_traffic_per_launch(config_name: str, fused: bool):
+    """Mean HBM bytes per launch of this config from the committed rocprofv3 PMC summaries
+    (profiles/<round>_pmc_fetch[_w3].summary.txt + <round>_pmc_write.summary.txt, collected by
+    tools/collect_profiles.sh with the same launch grouping): FETCH_SIZE [KiB] x 2 (gfx950 tallies the
+    128-B requests of wide coalesced reads at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE [KiB]."""
+    import re
+
+    names = {"7b-w4-s0": ("pmc_fetch.summary.txt", "pmc_write.summary.txt"), "7b-w3-s45": ("pmc_fetch_w3.summary.txt", None)}
+    if config_name not in names or not fused:
+        return None, None
+    prof = os.path.join(ROOT, "profiles")
+
+    def mean_kib(fname, counter):
+        try:
+            txt = open(os.path.join(prof, fname)).read()
+        except OSError:
+            return None
+        rows = re.findall(rf"grid=\d+\s+{counter}\s+n=(\d+)\s+mean=\s*([\d,\.]+)", txt)
+        if not rows:
+            return None
+        n = sum(int(a) for a, _ in rows)
+        return sum(int(a) * float(b.replace(",", "")) for a, b in rows) / n
+
+    for rnd in ("r02", "r01"):  # newest committed round first
+        fetch = mean_kib(f"{rnd}_{names[config_name][0]}", "FETCH_SIZE")
+        if fetch is None:
+            continue
+        wname = names[config_name][1]
+        write = mean_kib(f"{rnd}_{wname}", "WRITE_SIZE") if wname else 0.0
+        return int((2.0 * fetch + (write or 0.0)) * 1024), f"committed PMC summary profiles/{rnd}_{names[config_name][0]} (not a live measurement)"
+    return None, None
+
+
+def time_blocks(step, sync, steps, warmup, repeats):
+    """The contract's timed region (exactly `steps` steps between barrier + synchronize pairs), then
+    repeats - 1 more such blocks for the spread.  Returns the list of block times in seconds."""
+    for _ in range(warmup):
+        step()
+    out = []
+    for _ in range(max(1, repeats)):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        out.append(time.perf_counter() - t0)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0 of a 1-GPU run only, bounded samples)
+# ---------------------------------------------------------------------------------------------------
+def cpu_baseline_c_port(layers, model_layers: int, budget_s: float = 8.0):
+    """The C port (oracle/libsqllm_oracle.so, OpenMP over the host cores) on decoder layers of the same
+    workload until ~budget_s of CPU time is spent; scaled to a whole pass."""
+    import numpy as np
+
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libsqllm_oracle.so"))
     lib.sqo_matvec.restype = ctypes.c_int
     lib.sqo_num_threads.restype = ctypes.c_int
     threads = lib.sqo_num_threads()
@@ -110,40 +256,114 @@ def cpu_baseline(layers, model_layers: int, budget_s: float = 12.0):
         spent += dt
         done_layers += 1
     best = min(t_layers)  # the first layer pays page faults / thread start-up
-    return dict(value=1.0 / (best * model_layers), unit="tokens/s", cores=threads, kind="port",
-                sample=f"{done_layers} of {model_layers} decoder layers ({per_layer} linears each) of the same workload, "
-                       f"C port oracle/sqllm_oracle.c with OpenMP, best layer {best * 1e3:.1f} ms, scaled x{model_layers}")
+    return dict(value=round(1.0 / (best * model_layers), 3), unit="tokens/s", threads=threads,
+                sample=f"{done_layers} of {model_layers} decoder layers, best layer {best * 1e3:.1f} ms, scaled x{model_layers}")
 
 
-def pmc_traffic_per_launch(config_name: str, fused: bool):
-    """Mean HBM bytes per launch of this config from the committed rocprofv3 PMC summaries
-    (profiles/r01_pmc_fetch[_w3].summary.txt + r01_pmc_write.summary.txt, collected by
-    tools/collect_profiles.sh with the same launch grouping): FETCH_SIZE [KiB] x 2 (gfx950 tallies the
-    128-B requests of wide coalesced reads at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE [KiB]."""
-    import re
+def cpu_baseline_torch(layers, model_layers: int, budget_s: float = 6.0):
+    """The reference-style CPU path (BASELINE.json configs[0] / north_star): the codebook gather
+    W[n, k] = lookup_table[n, idx[k, n]] (indices unpacked by the product's tensor-level unpacker)
+    followed by torch.matmul, and torch.matmul alone on the pre-dequantised W, fp32, all host
+    cores.  Dense term only (the s0 headline); one decoder layer at a time until the budget is spent."""
+    import torch
 
-    names = {"7b-w4-s0": ("r01_pmc_fetch.summary.txt", "r01_pmc_write.summary.txt"),
-             "7b-w3-s45": ("r01_pmc_fetch_w3.summary.txt", None)}
-    if config_name not in names or not fused:
-        return None
-    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    from squeezellm_amd import pack
 
-    def mean_kib(fname, counter):
-        try:
-            txt = open(os.path.join(prof, fname)).read()
-        except OSError:
-            return None
-        rows = re.findall(rf"grid=\d+\s+{counter}\s+n=(\d+)\s+mean=\s*([\d,\.]+)", txt)
-        if not rows:
-            return None
-        n = sum(int(a) for a, _ in rows)
-        return sum(int(a) * float(b.replace(",", "")) for a, b in rows) / n
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    per_layer = len(layers) // model_layers
+    g = torch.Generator().manual_seed(0)
+    t_deq, t_mm, done, spent = [], [], 0, 0.0
+    while spent < budget_s and done < min(model_layers, 3):
+        ops = []
+        for lay in layers[done * per_layer:(done + 1) * per_layer]:
+            ops.append((lay["qweight"].cpu(), lay["lookup_table"].cpu(), lay["bits"], torch.randn(lay["K"], generator=g)))
+        t0 = time.perf_counter()
+        Ws = []
+        for q, lut, bits, x in ops:
+            idx = pack.unpack_qweight(q, bits).to(torch.int64)   # [K, N]
+            W = lut.gather(1, idx.t().contiguous())              # [N, K]
+            Ws.append(W)
+            _ = W @ x
+        t1 = time.perf_counter()
+        for _ in range(2):  # second pass: warm
+            t2 = time.perf_counter()
+            for W, (_, _, _, x) in zip(Ws, ops):
+                _ = W @ x
+            t3 = time.perf_counter()
+        t_deq.append(t1 - t0)
+        t_mm.append(t3 - t2)
+        spent += t3 - t0
+        done += 1
+        del Ws
+    return dict(cores=cores, threads=torch.get_num_threads(),
+                dequant_matmul_f32=dict(value=round(1.0 / (min(t_deq) * model_layers), 4), unit="tokens/s",
+                                        ms_per_decoder_layer=round(min(t_deq) * 1e3, 1)),
+                matmul_only_f32=dict(value=round(1.0 / (min(t_mm) * model_layers), 3), unit="tokens/s",
+                                     ms_per_decoder_layer=round(min(t_mm) * 1e3, 2)),
+                sample=f"{done} of {model_layers} decoder layers ({per_layer} linears each) of the same workload, dense term, "
+                       f"best layer scaled x{model_layers}")
 
-    fetch = mean_kib(names[config_name][0], "FETCH_SIZE")
-    if fetch is None:
-        return None
-    write = mean_kib(names[config_name][1], "WRITE_SIZE") if names[config_name][1] else 0.0
-    return int((2.0 * fetch + (write or 0.0)) * 1024)
+
+# ---------------------------------------------------------------------------------------------------
+# one replica-mode measurement of a config (used for the headline and for the sub-records)
+# ---------------------------------------------------------------------------------------------------
+def measure_replica(config_name, dev, rank, args, steps, warmup, repeats, sync, want_roofline):
+    import torch
+
+    from squeezellm_amd import decode, synth
+
+    cfg = CONFIGS[config_name]
+    spec = synth.MODEL_SHAPES[cfg["model"]]
+    model_layers = spec["layers"] if args.layers is None else args.layers
+    layers = build_layers(cfg, dev, 0, model_layers)
+    bytes_per_op = [synth.layer_bytes(l, 1) for l in layers]
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    xs, ys = decoder_inputs(layers, dev, gen)
+    seq = decode.OpSequence(layers, xs, ys, fuse_shared_input=not args.no_fuse)
+    if args.launch == "graph":
+        graph = seq.graph(warmup=1)
+        step = graph.replay
+    else:
+        step = seq.launch
+    blocks = time_blocks(step, sync, steps, warmup, repeats)
+    out = dict(cfg=cfg, model_layers=model_layers, per_layer=len(spec["linears"]), layers=layers, seq=seq,
+               bytes_per_op=bytes_per_op, blocks=blocks, roofline=None, per_layer_us=None)
+    if want_roofline:
+        out["roofline"], out["per_layer_us"] = roofline_leg(seq, layers, bytes_per_op, cfg, config_name, not args.no_fuse)
+    return out
+
+
+def batch_leg_13b(dev, args, sync):
+    """BASELINE.json configs[3]: LLaMA-13B shapes, w4 + 0.45 % sparse + top-10, batch 1..8 through the
+    operator the reference would pick (batch 1: the matvec op, quant.py:212; 2..8: the *_batched op),
+    over 4 decoder layers of distinct weights (0.7 GB), graph replay, plus per-launch kernel times."""
+    import torch
+
+    from squeezellm_amd import decode, synth
+
+    cfg = CONFIGS["13b-w4-s45"]
+    n_layers = 4 if args.layers is None else min(args.layers, 4)
+    layers = build_layers(cfg, dev, 0, n_layers)
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    rec = {}
+    for B in (1, 2, 4, 8):
+        xs, ys = decoder_inputs(layers, dev, gen, batch=0 if B == 1 else B)
+        seq = decode.OpSequence(layers, xs, ys, batched=B > 1, fuse_shared_input=not args.no_fuse)
+        graph = seq.graph(warmup=1)
+        blocks = time_blocks(graph.replay, sync, 20, 3, 3)
+        ms_layer = statistics.median(blocks) / 20 / n_layers * 1e3
+        bytes_per_op = [synth.layer_bytes(l, B) for l in layers]
+        seq.profile(reps=1)
+        us = seq.profile(reps=3)
+        rec[f"batch{B}"] = {"ms_per_decoder_layer": round(ms_layer, 4), "launches_per_decoder_layer": seq.n_groups // n_layers,
+                            "hbm_frac_wall": round(sum(bytes_per_op) / n_layers / (ms_layer * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "per_layer_us": per_shape_table(seq, layers, bytes_per_op, us)}
+        del xs, ys, seq, graph
+    del layers
+    torch.cuda.empty_cache()
+    return {"workload": f"llama-13b w4 s45 (0.45% CSR outliers + top-10 rows), {n_layers} decoder layers x 7 linears of distinct weights, "
+                        "batch 1 = matvec op, batch 2/4/8 = *_batched op, HIP-graph replay", **rec}
 
 
 def main():
@@ -151,7 +371,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from squeezellm_amd import decode, sharding, synth
+    from squeezellm_amd import sharding, synth
 
     cfg = CONFIGS[args.config]
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,47 +399,6 @@ def main():
         mode = "pipeline" if (world > 1 and args.config.startswith("65b")) else "replicas"
     if world == 1 and args.parallel != "pipeline":
         mode = "replicas"  # (an explicit --parallel pipeline on one GPU runs a ring of one stage)
-    lo, hi = sharding.partition_layers(model_layers, world)[rank] if mode == "pipeline" else (0, model_layers)
-
-    # ---- build this rank's layers (distinct weights per linear), resident in HBM ----
-    layers = []
-    for li in range(lo, hi):
-        for j, (lname, K, N) in enumerate(spec["linears"]):
-            lay = synth.make_layer(K, N, cfg["bits"], sparse_frac=cfg["sparse"], topX=cfg["topX"],
-                                   heavy_rows=10 if cfg["sparse"] > 0 else 0, device=dev, seed=li * per_layer + j)
-            lay["name"] = f"layers.{li}.{lname}"
-            layers.append(lay)
-    bytes_per_op = [synth.layer_bytes(l, 1) for l in layers]
-
-    if mode == "replicas":
-        g = torch.Generator(device=dev).manual_seed(1234 + rank)
-        # activations as in the decoder layer: q/k/v read the same hidden state, gate/up the same
-        # post-attention state, o_proj and down_proj their own inputs (model_parse.py:53-61)
-        shared = {"k_proj": "q_proj", "v_proj": "q_proj", "up_proj": "gate_proj"}
-        xs, last = [], {}
-        for l in layers:
-            lname = l["name"].rsplit(".", 1)[1]
-            src = shared.get(lname)
-            if src is not None and src in last:
-                xs.append(last[src])
-            else:
-                xs.append(torch.randn(l["K"], device=dev, generator=g, dtype=torch.float16).float())
-            last[lname] = xs[-1]
-        ys = [torch.zeros(l["N"], device=dev, dtype=torch.float32) for l in layers]
-        seq = decode.OpSequence(layers, xs, ys, fuse_shared_input=not args.no_fuse)
-        if args.launch == "graph":
-            graph = seq.graph(warmup=1)
-            step = graph.replay
-        else:
-            step = seq.launch
-        tokens_per_step = 1
-    else:
-        stage = sharding.DecodeStage(layers, hidden, dev, seed=rank)
-        g = torch.Generator(device=dev).manual_seed(99 + rank)
-        h0 = torch.randn(hidden, device=dev, generator=g, dtype=torch.float16)
-        pipe = sharding.RingPipeline(stage, hidden, rank=rank, world_size=world, device=dev, h0=h0)
-        step = lambda: pipe.run(world)  # noqa: E731  W ticks = every sequence advances one token
-        tokens_per_step = world
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -227,23 +406,39 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    single = world == 1 and rank == 0 and mode == "replicas"
+    extra = {}
+    if mode == "replicas":
+        m = measure_replica(args.config, dev, rank, args, args.steps, args.warmup, args.repeats, sync,
+                            want_roofline=single and not args.no_roofline)
+        blocks, seq, layers = m["blocks"], m["seq"], m["layers"]
+        bytes_per_op = m["bytes_per_op"]
+        tokens_per_step = 1
+    else:
+        lo, hi = sharding.partition_layers(model_layers, world)[rank]
+        layers = build_layers(cfg, dev, lo, hi)
+        bytes_per_op = [synth.layer_bytes(l, 1) for l in layers]
+        stage = sharding.DecodeStage(layers, hidden, dev, seed=rank)
+        g = torch.Generator(device=dev).manual_seed(99 + rank)
+        h0 = torch.randn(hidden, device=dev, generator=g, dtype=torch.float16)
+        pipe = sharding.RingPipeline(stage, hidden, rank=rank, world_size=world, device=dev, h0=h0)
+        step = lambda: pipe.run(world)  # noqa: E731  W ticks = every sequence advances one token
+        blocks = time_blocks(step, sync, args.steps, args.warmup, args.repeats)
+        tokens_per_step = world
+        seq, m = None, None
+        extra["pipeline_tick_us"] = round(statistics.median(blocks) / args.steps / world * 1e6, 2)
 
+    if use_dist:  # every block: MAX over ranks
+        t = torch.tensor(blocks, device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        blocks = [float(v) for v in t.tolist()]
+    elapsed = blocks[0]  # the contract's timed region: exactly --steps steps
     ms_per_step = elapsed / args.steps * 1e3
     # replicas: every rank produced `steps` tokens of its own stream; pipeline: the job as a whole
     # produced `world` tokens per step
-    value = (world if mode == "replicas" else tokens_per_step) * args.steps / elapsed
+    per_job = world if mode == "replicas" else tokens_per_step
+    value = per_job * args.steps / elapsed
+    ms_all = [b / args.steps * 1e3 for b in blocks]
 
     result = {
         "metric": "LLaMA-7B-shaped quantised-linear decode throughput (batch 1, all QuantLinearLUT matvecs of the model per token)"
@@ -259,6 +454,9 @@ def main():
         "vs_baseline": None,  # BASELINE.md holds no published number for this metric
         "dtype": "f32",  # fp32 LUT values, fp32 activations, fp32 accumulate (3/4-bit integer indices)
         "data": "synthetic",
+        "repeats": {"blocks_of_steps": len(ms_all), "ms_per_step": [round(v, 4) for v in ms_all],
+                    "ms_per_step_median": round(statistics.median(ms_all), 4), "ms_per_step_min": round(min(ms_all), 4),
+                    "value_median": round(per_job * 1e3 / statistics.median(ms_all), 2), "value_best": round(per_job * 1e3 / min(ms_all), 2)},
         "config": {
             "workload": f"{cfg['model']} w{cfg['bits']} " + (f"s{int(round(cfg['sparse'] * 10000))} (0.45% CSR outliers + top-{cfg['topX']} rows)" if cfg["sparse"] else "s0 (dense-only)")
                         + f", batch=1 decode, {model_layers} layers x {per_layer} linears, op {cfg['op']}",
@@ -271,55 +469,55 @@ def main():
                 f"dp{world}: independent token streams, one full model replica per GPU, no data-path collective"
                 if mode == "replicas" else
                 f"pp{world}: layer-sharded ring pipeline, RCCL all-gather of the hidden state per tick"),
+            "world_size": world,
+            "rccl_ranks": dist.get_world_size() if use_dist else 0,  # 0: no process group (single process)
             "ops_per_token": model_layers * per_layer,
             "algorithmic_bytes_per_token": int(sum(bytes_per_op)) if mode == "replicas" else None,
         },
     }
+    result.update(extra)
 
-    if world == 1 and rank == 0 and mode == "replicas":
+    if single:
         pass_bytes = float(sum(bytes_per_op))
-        result["hbm_frac_wall"] = round(pass_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        if not args.no_roofline:
-            import numpy as np
-
-            seq.profile(reps=1)  # warm
-            us = seq.profile(reps=5)  # one entry per launch (= per group of fused linears)
-            avg_us = float(us.mean())
-            n_launch = seq.n_groups
-            achieved = pass_bytes / n_launch / (avg_us * 1e-6) / 1e9
-            result["roofline"] = {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                # HBM bytes per launch from the PMC counters: they cannot be read live (rocprofv3 --pmc
-                # passes, one counter group each), so this is the committed summary of those passes
-                # for this config, gfx950 correction applied (FETCH_SIZE x 2); null if none is committed
-                "traffic": pmc_traffic_per_launch(args.config, not args.no_fuse),
-                "kernel": f"sqllm_fused_matvec<{cfg['bits']},1>",
-                "avg_kernel_us": round(avg_us, 3),
-                "launches_per_step": n_launch,
-                "algorithmic_bytes_per_launch": int(pass_bytes / n_launch),
-                "sum_kernel_ms_per_step": round(float(us.sum()) * 1e-3, 4),
-            }
-            # per-layer matvec microseconds by shape (the other half of BASELINE.json's metric)
-            table = {}
-            for grp, u in zip(seq.groups, us):
-                key = "+".join(f"{layers[i]['K']}x{layers[i]['N']}" for i in grp)
-                table.setdefault(key, []).append((u, sum(bytes_per_op[i] for i in grp)))
-            per_shape = {}
-            for key, lst in table.items():
-                u = np.array([a for a, _ in lst])
-                b = lst[0][1]
-                per_shape[key] = {"us_mean": round(float(u.mean()), 3), "us_min": round(float(u.min()), 3),
-                                  "MB": round(b / 1e6, 3), "GBps": round(b / (u.mean() * 1e-6) / 1e9, 1),
-                                  "hbm_frac": round(b / (u.mean() * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
-            result["per_layer_us"] = per_shape
+        result["hbm_frac_wall"] = round(pass_bytes / (statistics.median(ms_all) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if m["roofline"] is not None:
+            result["roofline"] = m["roofline"]
+            result["per_layer_us"] = m["per_layer_us"]
             if args.per_shape:
-                print(json.dumps(per_shape, indent=1), file=sys.stderr)
+                print(json.dumps(m["per_layer_us"], indent=1), file=sys.stderr)
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(layers, model_layers)
+            # value = the reference-style path BASELINE.json names (torch dequant + matmul on the host
+            # cores); the other CPU legs ride along
+            cp = cpu_baseline_c_port(layers, model_layers)  # first: torch's OpenMP pool would spin beside it
+            tb = cpu_baseline_torch(layers, model_layers)
+            result["cpu_baseline"] = {
+                "value": tb["dequant_matmul_f32"]["value"], "unit": "tokens/s", "cores": tb["cores"], "kind": "port",
+                "sample": "torch codebook gather + torch.matmul, fp32, " + tb["sample"],
+                "paths": {"torch_dequant_matmul_f32": tb["dequant_matmul_f32"], "torch_matmul_only_f32": tb["matmul_only_f32"],
+                          "c_port_openmp": cp},
+            }
+        # release the headline model before the sub-records build theirs
+        headline_default = args.config == "7b-w4-s0" and args.layers is None and not args.no_fuse and args.launch == "graph"
+        del m, seq, layers
+        torch.cuda.empty_cache()
+        if headline_default and not args.no_sub_records:
+            sub = {}
+            for name in SUB_RECORD_CONFIGS:
+                s = measure_replica(name, dev, rank, args, 20, 3, 3, sync, want_roofline=not args.no_roofline)
+                ms = [b / 20 * 1e3 for b in s["blocks"]]
+                pb = float(sum(s["bytes_per_op"]))
+                sub[name] = {
+                    "workload": f"{s['cfg']['model']} w{s['cfg']['bits']} s45 (0.45% CSR outliers + top-10 rows), batch=1 decode, op {s['cfg']['op']}",
+                    "value": round(1e3 / statistics.median(ms), 2), "unit": "tokens/s", "steps": 20, "blocks_of_steps": len(ms),
+                    "ms_per_step_median": round(statistics.median(ms), 4), "ms_per_step_min": round(min(ms), 4),
+                    "hbm_frac_wall": round(pb / (statistics.median(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "algorithmic_bytes_per_token": int(pb), "launches_per_token": s["seq"].n_groups,
+                    "roofline": s["roofline"], "per_layer_us": s["per_layer_us"],
+                }
+                del s
+                torch.cuda.empty_cache()
+            sub["13b-w4-s45-batched"] = batch_leg_13b(dev, args, sync)
+            result["sub_records"] = sub
 
     if rank == 0:
         print(json.dumps(result))

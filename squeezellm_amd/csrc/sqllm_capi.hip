@@ -19,7 +19,7 @@ std::atomic<int> g_cu_count{0};
 std::atomic<int> g_ablate{0};
 std::atomic<int> g_sparse_last{0};
 std::atomic<int> g_ablate_csr{0};
-std::atomic<int> g_mfma_min_batch{6};  // *_batched ops with at least this many rows take the matrix-core kernel
+std::atomic<int> g_mfma_min_batch{9};  // *_batched ops with at least this many rows take the matrix-core kernel
 std::atomic<void*> g_timeline{nullptr};  // measurement build: per-workgroup timestamp buffer
 
 int cu_count() {

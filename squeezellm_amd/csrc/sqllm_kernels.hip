@@ -1364,7 +1364,8 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
 // 30 us for 1..16 rows with the matrix pipe 50 % busy (rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES: all
 // workgroups are resident at once and run their prologue / matrix / epilogue phases in step),
 // 47-51 TFLOP/s from 32 rows up -- against 38 us (8 rows), 74 us (16 rows) and 37 TFLOP/s for the
-// 8-row batch tiles; hence the default switch-over at 6 rows.
+// 8-row batch tiles (which also serve q/k/v and gate/up as ONE launch); hence the default switch-over
+// at 9 rows, where the tiles would need a second pass.
 // Batches beyond 64 rows put the next 64 rows in the next blockIdx.y: the weights of a workgroup's
 // slice (<= 256 KB) are then re-read from L2 / Infinity Cache, not from HBM.
 // vec reaches the A operands through a PRIVATE LDS tile per wave (the waves of a workgroup work on

@@ -74,8 +74,8 @@ def test_plan_geometry():
     assert p3["grid_x"] >= p3["dense_blocks"] + p3["csr_blocks"] + p3["topx_blocks"]
     assert (p3["grid_x"] - p3["dense_blocks"]) % 8 == 0  # dense ids stay XCD-aligned
     assert _lib.plan_query(4, 4096, 4096, batch=3)["grid_y"] == 1
-    # batches from `mfma_min_batch` (6) rows up take the matrix-core kernel: passes of 16 / 32 / 64 rows
-    assert _lib.get_option("mfma_min_batch") == 6
+    # batches from `mfma_min_batch` (9) rows up take the matrix-core kernel: passes of 16 / 32 / 64 rows
+    assert _lib.get_option("mfma_min_batch") == 9
     assert _lib.plan_query(4, 4096, 4096, batch=9)["grid_y"] == 1
     assert _lib.plan_query(4, 4096, 4096, batch=33)["grid_y"] == 1
     assert _lib.plan_query(4, 4096, 4096, batch=2048)["grid_y"] == 32
@@ -83,7 +83,7 @@ def test_plan_geometry():
     assert pm["groups_per_wave"] % 32 == 0 and pm["k_slices"] * pm["groups_per_wave"] >= 5120 // 8
     _lib.set_option("mfma_min_batch", 1 << 30)  # ... unless switched off: batch tiles of 8
     assert _lib.plan_query(4, 4096, 4096, batch=9)["grid_y"] == 2
-    _lib.set_option("mfma_min_batch", 6)
+    _lib.set_option("mfma_min_batch", 9)
     # options round-trip and steer the plan
     _lib.set_option("target_wgs", 1024)
     assert _lib.get_option("target_wgs") == 1024

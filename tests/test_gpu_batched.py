@@ -1,5 +1,5 @@
 """GPU parity of the *_batched operators beyond the 8-row batch tiles: the matrix-core kernel
-(batches of `mfma_min_batch` = 6 rows and more), at the batch sizes the reference's callers use --
+(batches of `mfma_min_batch` = 9 rows and more), at the batch sizes the reference's callers use --
 PPL evaluation runs the batched ops with B = 2048 (/root/reference/llama.py:91-103 ->
 squeezellm/quant.py:313-383) -- and at the BASELINE.json configurations that name a batch:
 config 1 (OPT-1.3B shapes with bias, batch 1 x seq 128 -> B = 128) and config 4 (LLaMA-13B shapes,
@@ -37,7 +37,7 @@ def run_batched(qc, gpu, case, kind, batch, seed=1):
 
 @pytest.mark.parametrize("bits,K,N", [(4, 256, 192), (3, 96 * 2, 260), (4, 1024, 132), (3, 1024, 776), (4, 32, 4), (3, 32, 8)])
 @pytest.mark.parametrize("kind", ["dense", "spmv", "hybrid"])
-@pytest.mark.parametrize("batch", [6, 16, 17, 33, 64, 65, 130])
+@pytest.mark.parametrize("batch", [9, 16, 17, 33, 64, 65, 130])
 def test_wide_batches_vs_oracle(qc, gpu, bits, K, N, kind, batch):
     """One, two and four row blocks of 16, several passes of 64 rows, ragged ends in every dimension
     (N not a multiple of the 64-column tile, K = 32: a single unit, fewer units than lane rows)."""
@@ -74,7 +74,7 @@ def test_both_batched_paths_agree(qc, gpu, bits):
             torch.cuda.synchronize()
             outs.append(y.cpu().numpy())
     finally:
-        _lib.set_option("mfma_min_batch", 6)
+        _lib.set_option("mfma_min_batch", 9)
     assert H.rel_err(outs[1], outs[0]) <= 1e-5
 
 
@@ -85,8 +85,8 @@ LLAMA13B = [(5120, 5120), (5120, 13824), (13824, 5120)]
 @pytest.mark.parametrize("K,N", LLAMA13B)
 @pytest.mark.parametrize("batch", [2, 8, 16])
 def test_llama13b_shapes_batched_hybrid(qc, gpu, bits, K, N, batch):
-    """BASELINE config 4 at full size on all three 13B shapes, against the C oracle (batch 2: batch
-    tiles; 8 and 16: matrix cores)."""
+    """BASELINE config 4 at full size on all three 13B shapes, against the C oracle (batch 2 and 8: batch
+    tiles; 16: matrix cores)."""
     case = H.make_case(bits, K, N, sparse=0.0045, topX=10, heavy_rows=10, seed=13)
     x, mul, got = run_batched(qc, gpu, case, "hybrid", batch)
     ref = H.c_matvec(H.c_oracle(), case, x, mul, batched=True)

@@ -18,7 +18,7 @@ for rep in range(reps):
     for v in values:
         for c in configs:
             _lib.set_option(name, v)
-            sys.argv = ["bench.py", "--config", c, "--no-cpu-baseline", "--steps", "40"]
+            sys.argv = ["bench.py", "--config", c, "--no-cpu-baseline", "--no-sub-records", "--steps", "40"]
             buf = io.StringIO()
             try:
                 with redirect_stdout(buf):
