@@ -18,3 +18,9 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC \
   -Wno-unused-value -Wno-deprecated-declarations \
   "$here/ref_shim/ref_capi.hip" -o "$here/_ref/libsqllm_ref.so"
 echo "built $here/_ref/libsqllm_ref.so"
+# Stage the reference's UNMODIFIED QuantLinearLUT module next to it (git-ignored like the .so, and
+# travelling with the gpurun snapshot like the .so): tests/test_gpu_reference_forward.py runs ITS
+# forward() -- the caller the drop-in claim is about -- on the real kernels of this repository.
+mkdir -p "$here/_ref/reference_py"
+cp "$ref/squeezellm/quant.py" "$here/_ref/reference_py/quant.py"
+echo "staged $here/_ref/reference_py/quant.py (unmodified copy of $ref/squeezellm/quant.py)"

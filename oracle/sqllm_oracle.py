@@ -234,7 +234,7 @@ def quantlinear_forward(x, layer: dict, acc=np.float64):
     matvec branch (x.shape[-1] == x.numel(), quant.py:212): y = bias.clone() or zeros (:214-219),
     x.float() (:223/:267), op, y.to(x.dtype).reshape(outshape) (:311-312).
     batched branch (:313-383): x.reshape(-1, K), out = zeros [B, N] fp32, op, out.to(dtype),
-    reshape, + bias AFTER the cast (:380-383).
+    reshape, + bias AFTER the cast (:380-383; the result takes the promoted dtype of out and bias).
 
     `layer` keys: bits, qweight, lookup_table, bias (or None), and optionally rows/cols/vals,
     full_rows/full_row_indices.  Op selection order hybrid -> spmv -> dense follows :224-265.
@@ -256,7 +256,9 @@ def quantlinear_forward(x, layer: dict, acc=np.float64):
     out = matvec(x2, layer["qweight"], np.zeros((x2.shape[0], N), np.float32), layer["lookup_table"], layer["bits"], acc=acc, **sparse)
     out = out.astype(dtype).reshape(x.shape[:-1] + (N,))
     if bias is not None:
-        out = out + np.asarray(bias).astype(dtype)
+        # `out + self.bias` (quant.py:382): a plain add, so an fp32 bias buffer promotes an fp16 `out`
+        # to fp32 -- torch's and numpy's type promotion agree here
+        out = out + np.asarray(bias)
     return out
 
 

@@ -91,9 +91,10 @@ class QuantLinearLUT(nn.Module):
         out = torch.zeros((x2.shape[0], self.outfeatures), device=x.device, dtype=torch.float32)
         self._call(x2.float().contiguous(), out, batched=True)
         out = out.to(dtype).reshape(*x.shape[:-1], self.outfeatures)
-        # (the reference writes `out + self.bias`; with an fp32 bias buffer that silently promotes an
-        # fp16 result to fp32 -- here the result keeps the input dtype)
-        return out + self.bias.to(dtype) if self.bias is not None else out
+        # `out + self.bias` exactly as the reference writes it (quant.py:382): with the fp32 bias buffer
+        # the constructor registers, an fp16 result is promoted to fp32 (checked against the unmodified
+        # reference module in tests/test_gpu_reference_forward.py)
+        return out + self.bias if self.bias is not None else out
 
     # -- MI355X-side conveniences -------------------------------------------------------------
     @classmethod

@@ -33,7 +33,9 @@ def test_quantlinear_forward_vs_oracle(gpu, bits, cfg, dtype):
         x = torch.randn(shape, device=gpu, generator=g).to(tdt)
         y = mod(x)
         ref = H.oracle.quantlinear_forward(x.cpu().numpy(), npl)
-        assert y.shape == ref.shape and y.dtype == tdt
+        # (matvec branch: the input dtype; batched branch: `out.to(dtype) + bias`, promoted by the fp32 bias)
+        assert y.shape == ref.shape and y.dtype == torch.from_numpy(ref[:0]).dtype
+        assert y.dtype == (tdt if len(shape) == 1 or shape[:-1] == (1, 1) else torch.float32)
         assert H.rel_err(y.float().cpu().numpy(), ref.astype(np.float32)) <= tol
 
 
