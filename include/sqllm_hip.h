@@ -41,7 +41,7 @@ extern "C" {
 #define SQLLM_E_SHAPE (-2)     /* K % 32 != 0, N % 4 != 0, height != K/32*bits, non-positive dims */
 #define SQLLM_E_NULL (-3)      /* a required pointer is NULL */
 #define SQLLM_E_ALIGN (-4)     /* qweight not 16-byte aligned */
-#define SQLLM_E_SPARSE (-5)    /* inconsistent sparse operands (nnz < 0, num_rows != N, topX < 0) */
+#define SQLLM_E_SPARSE (-5)    /* inconsistent sparse operands (nnz < 0, num_rows != N, topX < 0; with "validate_csr": bad rows[]) */
 #define SQLLM_E_BATCH (-6)     /* batch < 1 or vec_height != K for a batched op */
 #define SQLLM_E_OPTION (-7)    /* unknown option name / bad value */
 #define SQLLM_E_GROUP (-8)     /* group of 0 or > 4 ops, or members differ in vec / K / bits / batch */
@@ -245,6 +245,14 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *   "groups_per_wave" force the K units each wave walks (default 0 = derived from target_wgs)
  *   "sparse_last"     1 = CSR / top-X workgroups after the dense ones in the grid (default 0)
  *   "cu_count"        override the CU count used for planning (GPU-less tests)
+ *   "mfma_min_batch"  *_batched ops with at least this many rows run on the fp32 matrix cores
+ *                     (default 9: the 8-row batch tiles serve smaller batches in one pass)
+ *   "validate_csr"    debugging aid, default 0.  1 = before every launch that carries a CSR term,
+ *                     check ON THE DEVICE that rows[] is non-decreasing with rows[0] == 0 and
+ *                     rows[N] == nnz, and return SQLLM_E_SPARSE otherwise.  Blocks the host (one
+ *                     tiny kernel, a 4-byte read-back, a stream synchronise; 4 bytes of device
+ *                     memory are allocated on first use); skipped while the stream is capturing.
+ *                     Meant for the fused linear, which counts on `rows` to detect completion.
  * Returns SQLLM_E_OPTION for an unknown name. */
 int sqllm_set_option(const char* name, int value);
 int sqllm_get_option(const char* name, int* value);

@@ -19,7 +19,8 @@ std::atomic<int> g_cu_count{0};
 std::atomic<int> g_ablate{0};
 std::atomic<int> g_sparse_last{0};
 std::atomic<int> g_ablate_csr{0};
-std::atomic<int> g_mfma_min_batch{9};  // *_batched ops with at least this many rows take the matrix-core kernel
+std::atomic<int> g_mfma_min_batch{9};
+std::atomic<int> g_validate_csr{0};    // debug: check rows[] on the device before every launch that carries a CSR term  // *_batched ops with at least this many rows take the matrix-core kernel
 std::atomic<void*> g_timeline{nullptr};  // measurement build: per-workgroup timestamp buffer
 
 int cu_count() {
@@ -56,6 +57,15 @@ int validate(const sqllm_op* op) {
     if (op->topX > 0 && !op->full_row_indices) return SQLLM_E_NULL;
   }
   return SQLLM_OK;
+}
+
+// option "validate_csr": a value check of rows[] on the device (blocks the host; debugging aid)
+int validate_csr_values(const sqllm_op* op, sqllm_stream_t stream) {
+  if (!g_validate_csr.load(std::memory_order_relaxed) || !op->rows || op->nnz <= 0) return SQLLM_OK;
+  int bad = 0;
+  hipError_t e = sqllm::check_csr(op->rows, op->N, op->nnz, static_cast<hipStream_t>(stream), &bad);
+  if (e != hipSuccess) return static_cast<int>(e);
+  return bad ? SQLLM_E_SPARSE : SQLLM_OK;
 }
 
 // Launch geometry.  The dense part is cut into 64-column tiles x K slices so that about `target`
@@ -172,6 +182,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "sparse_last")) { g_sparse_last.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { g_cu_count.store(value); return SQLLM_OK; }  // for GPU-less planning tests
   if (!strcmp(name, "mfma_min_batch")) { g_mfma_min_batch.store(value < 1 ? 1 : value); return SQLLM_OK; }
+  if (!strcmp(name, "validate_csr")) { g_validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
 #ifdef SQLLM_ABLATION_BUILD
   if (!strcmp(name, "ablate")) { g_ablate.store(value); return SQLLM_OK; }
   if (!strcmp(name, "ablate_csr")) { g_ablate_csr.store(value); return SQLLM_OK; }
@@ -185,6 +196,7 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "groups_per_wave")) { *value = g_groups_per_wave.load(); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { *value = g_cu_count.load(); return SQLLM_OK; }
   if (!strcmp(name, "mfma_min_batch")) { *value = g_mfma_min_batch.load(); return SQLLM_OK; }
+  if (!strcmp(name, "validate_csr")) { *value = g_validate_csr.load(); return SQLLM_OK; }
   return SQLLM_E_OPTION;
 }
 
@@ -229,6 +241,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     for (int i = 0; i < n; ++i) {
       const sqllm_op* op = &ops[i];
       int rc = validate(op);
+      if (rc == SQLLM_OK) rc = validate_csr_values(op, stream);
       if (rc != SQLLM_OK) return rc;
       if (op->vec != ops[0].vec || op->K != ops[0].K || op->bits != ops[0].bits || op->batch != ops[0].batch)
         return SQLLM_E_GROUP;
@@ -246,8 +259,8 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       sg.rows = op->rows;
       sg.cols = op->cols;
       sg.vals = op->vals;
-      sg.full_rows = op->full_rows;
-      sg.full_idx = op->full_row_indices;
+      sg.full_rows = op->topX > 0 ? op->full_rows : nullptr;
+      sg.full_idx = op->topX > 0 ? op->full_row_indices : nullptr;
       make_plan_mfma(op, &sg.gm);
       a.ga.block0[0] = 0;
       for (int j = 1; j <= sqllm::kMaxSegments; ++j) a.ga.block0[j] = sg.gm.dense_block0 + sg.gm.dense_blocks;
@@ -276,6 +289,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
   for (int i = 0; i < n; ++i) {
     const sqllm_op* op = &ops[i];
     int rc = validate(op);
+    if (rc == SQLLM_OK) rc = validate_csr_values(op, stream);
     if (rc != SQLLM_OK) return rc;
     if (op->vec != ops[0].vec || op->K != ops[0].K || op->bits != ops[0].bits ||
         (op->batch <= 0 ? 1 : op->batch) != (ops[0].batch <= 0 ? 1 : ops[0].batch))
@@ -287,8 +301,9 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     sg.rows = op->rows;
     sg.cols = op->cols;
     sg.vals = op->vals;
-    sg.full_rows = op->full_rows;
-    sg.full_idx = op->full_row_indices;
+    // (full_rows without columns is no term at all: the kernels key the top-X work on the pointer)
+    sg.full_rows = op->topX > 0 ? op->full_rows : nullptr;
+    sg.full_idx = op->topX > 0 ? op->full_row_indices : nullptr;
     sg.bias = nullptr;
     sg.out16 = nullptr;
 #ifdef SQLLM_ABLATION_BUILD

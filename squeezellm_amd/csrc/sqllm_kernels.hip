@@ -1779,6 +1779,30 @@ hipError_t launch_batched_mfma(int bits, const LaunchArgs& a, hipStream_t stream
   return bits == 4 ? launch_mfma_bits<4>(a, stream) : launch_mfma_bits<3>(a, stream);
 }
 
+// Debug aid (option "validate_csr"): is `rows` a CSR row-pointer array for nnz values?  The fused
+// linear detects completion by counting the contributions `rows` announces, so an inconsistent
+// array leaves columns unfinished and the workspace dirty; this check makes that a loud error.
+// Blocks the host (one tiny kernel + a 4-byte read-back); skipped while the stream is capturing.
+__global__ void sqllm_check_csr(const int* __restrict__ rows, int N, int nnz, int* flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && (rows[0] != 0 || rows[N] != nnz)) atomicOr(flag, 1);
+  if (i < N && rows[i + 1] < rows[i]) atomicOr(flag, 2);
+}
+
+hipError_t check_csr(const int* rows, int N, int nnz, hipStream_t stream, int* bad) {
+  *bad = 0;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return hipSuccess;
+  static int* flag = nullptr;  // 4 bytes of device memory, allocated on first use of the debug option
+  hipError_t e;
+  if (!flag && (e = hipMalloc(&flag, sizeof(int))) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(flag, 0, sizeof(int), stream)) != hipSuccess) return e;
+  hipLaunchKernelGGL(sqllm_check_csr, dim3((N + 255) / 256), dim3(256), 0, stream, rows, N, nnz, flag);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(bad, flag, sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  return hipStreamSynchronize(stream);
+}
+
 hipError_t launch_fused(int bits, const LaunchArgs& a, hipStream_t stream) {
 #ifdef SQLLM_ABLATION_BUILD
   if (a.ablate >= 100) return launch_calib(a, stream);

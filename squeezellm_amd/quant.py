@@ -102,8 +102,11 @@ class QuantLinearLUT(nn.Module):
         """Wrap already-packed operands (e.g. squeezellm_amd.synth.make_layer) without copying."""
         nnz = 0 if layer.get("vals") is None else layer["vals"].numel()
         topX = 0 if layer.get("full_rows") is None else layer["full_rows"].shape[1]
+        # a layer whose outliers ALL moved into full_rows (pack_layer with every outlier in <= topX
+        # rows) has an empty CSR but still needs the hybrid op: the sparse path is on whenever either
+        # term exists
         m = cls(layer["bits"], layer["K"], layer["N"], layer.get("bias") is not None,
-                include_sparse=nnz > 0, numvals=nnz, topX=topX, balanced=balanced)
+                include_sparse=nnz > 0 or topX > 0, numvals=nnz, topX=topX, balanced=balanced)
         m.qweight, m.lookup_table = layer["qweight"], layer["lookup_table"]
         if layer.get("bias") is not None:
             m.bias = layer["bias"]
@@ -111,6 +114,11 @@ class QuantLinearLUT(nn.Module):
             m.rows, m.cols, m.vals = layer["rows"], layer["cols"], layer["vals"]
             if balanced:
                 m.startrows = torch.zeros(m.num_threads, dtype=torch.int32, device=layer["vals"].device)
+        elif topX:  # empty CSR operands for the hybrid op (the constructor registers none for numvals == 0)
+            dev = layer["qweight"].device
+            m.rows = layer["rows"] if layer.get("rows") is not None else torch.zeros(layer["N"] + 1, dtype=torch.int32, device=dev)
+            m.cols = torch.zeros(0, dtype=torch.int32, device=dev)
+            m.vals = torch.zeros(0, dtype=torch.float32, device=dev)
         if topX:
             m.full_rows, m.full_row_indices = layer["full_rows"], layer["full_row_indices"]
         return m
@@ -138,6 +146,21 @@ class QuantLinearLUTFused(QuantLinearLUT):
             cache[device] = ws
         return ws
 
+    def _check_csr_once(self) -> None:
+        """The fused kernel detects completion by COUNTING the contributions `rows` announces: an
+        inconsistent CSR (rows not non-decreasing, rows[N] != nnz -- e.g. buffers not loaded yet)
+        would leave columns unfinished and the shared workspace dirty for every later call.  Checked
+        once per module and CSR buffer (one device round trip), so that it fails loudly instead."""
+        key = (self.rows.data_ptr(), self.vals.data_ptr(), self.vals.numel())
+        if self.__dict__.get("_csr_ok") == key:
+            return
+        r = self.rows
+        ok = r.numel() == self.outfeatures + 1 and bool((r[1:] >= r[:-1]).all()) and int(r[0]) == 0 and int(r[-1]) == self.vals.numel()
+        if not ok:
+            raise ValueError("QuantLinearLUTFused: inconsistent CSR operands (rows must be non-decreasing with rows[0] == 0 and "
+                             "rows[N] == vals.numel()); the fused kernel counts contributions from `rows`")
+        self.__dict__["_csr_ok"] = key
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dtype != torch.float16 or not x.is_cuda:
             return super().forward(x)
@@ -155,9 +178,10 @@ class QuantLinearLUTFused(QuantLinearLUT):
         o.bits, o.batch, o.K, o.N = self.bits, batch, K, N
         o.vec, o.qweight, o.mul, o.lookup_table = x2.data_ptr(), self.qweight.data_ptr(), out.data_ptr(), self.lookup_table.data_ptr()
         if self.include_sparse and self.numvals > 0:
+            self._check_csr_once()
             o.rows, o.cols, o.vals, o.nnz = self.rows.data_ptr(), self.cols.data_ptr(), self.vals.data_ptr(), self.vals.numel()
-            if self.topX > 0:
-                o.full_rows, o.full_row_indices, o.topX = self.full_rows.data_ptr(), self.full_row_indices.data_ptr(), self.topX
+        if self.include_sparse and self.topX > 0:  # independent of the CSR term (which may be empty)
+            o.full_rows, o.full_row_indices, o.topX = self.full_rows.data_ptr(), self.full_row_indices.data_ptr(), self.topX
         lin.bias = None if self.bias is None else self.bias.data_ptr()
         lin.workspace = self._workspace(batch, x.device).data_ptr()
         with quant_cuda._on_device_of(x) as stream:

@@ -9,15 +9,35 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+NEEDS_LIB = ("test_capi_cpu.py", "test_codegen_cpu.py")  # CPU-side tests that load libsqllm_hip.so
+_lib_problem = None
+
+
 def pytest_configure(config):
+    """Make sure the built artefacts exist (both are git-ignored).  On a host without ROCm the HIP
+    library cannot be built: the pure-CPU tests (oracle, packer, checkpoint format) still run, the
+    tests that need the library are skipped with the reason."""
+    global _lib_problem
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run under gpurun)")
-    # make sure the built artefacts exist (both are git-ignored)
     from squeezellm_amd import build as sq_build
 
-    sq_build.build()
+    try:
+        sq_build.build()
+    except RuntimeError as e:  # hipcc missing or failing
+        if not os.path.exists(sq_build.LIB_PATH):
+            _lib_problem = str(e).splitlines()[0]
     if not os.path.exists(os.path.join(ROOT, "oracle", "libsqllm_oracle.so")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "libsqllm_oracle.so"], check=True,
                        capture_output=True)
+
+
+def pytest_collection_modifyitems(config, items):
+    if _lib_problem is None:
+        return
+    skip = pytest.mark.skip(reason=f"libsqllm_hip.so unavailable: {_lib_problem}")
+    for item in items:
+        if item.get_closest_marker("gpu") or os.path.basename(str(item.fspath)) in NEEDS_LIB:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -237,3 +237,72 @@ def test_c_abi_demo_builds_and_runs_without_python_in_the_loop(gpu, tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "ok (ABI version 1)" in res.stdout and "more than one fp16 ulp: 0 of" in res.stdout
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+def test_all_outliers_in_full_rows_keeps_the_topx_term(gpu, bits):
+    """A layer whose outliers all moved into full_rows has an EMPTY CSR (nnz == 0) but a top-X term:
+    it must still dispatch the hybrid op, through the operator path and through the fused linear
+    (round-1 advisor finding: from_operands gated the top-X term on nnz > 0)."""
+    import torch
+
+    from squeezellm_amd import quant
+
+    K, N = 256, 192
+    case = H.make_case(bits, K, N, topX=3, seed=17)
+    case.update(rows=np.zeros(N + 1, np.int32), cols=np.zeros(0, np.int32), vals=np.zeros(0, np.float32))
+    lay = H.to_torch(case, gpu)
+    lay["bias"] = None
+    mod = quant.QuantLinearLUT.from_operands(lay)
+    assert mod.include_sparse and mod.op_kind(False) == "spmv_hybrid" and mod.op_kind(True) == "spmv_hybrid"
+    layer = dict(case, bias=None)
+    rng = np.random.default_rng(4)
+    for shape in ((K,), (5, K), (12, K)):
+        x = rng.normal(size=shape).astype(np.float16)
+        ref = H.oracle.quantlinear_forward(x, layer).astype(np.float32)
+        assert np.abs(ref - H.oracle.quantlinear_forward(x, dict(layer, full_rows=None, full_row_indices=None, rows=None)).astype(np.float32)).max() > 0
+        y = mod(torch.from_numpy(x).to(gpu))
+        assert H.rel_err(y.float().cpu().numpy(), ref) <= 2e-3
+    fused = quant.QuantLinearLUT.from_operands(lay)
+    fused.__class__ = quant.QuantLinearLUTFused
+    x = rng.normal(size=(3, K)).astype(np.float16)
+    y = fused(torch.from_numpy(x).to(gpu))
+    assert H.rel_err(y.float().cpu().numpy(), H.oracle.quantlinear_forward(x, layer).astype(np.float32)) <= 2e-3
+
+
+def test_inconsistent_csr_fails_loudly(gpu):
+    """The fused linear counts contributions from `rows`; an inconsistent CSR must raise instead of
+    leaving columns unfinished and the workspace dirty: once per module in QuantLinearLUTFused, and
+    on every launch behind the C ABI's "validate_csr" debug option."""
+    import torch
+
+    from squeezellm_amd import _lib, quant, quant_cuda as qc, synth
+
+    lay = synth.make_layer(256, 128, 4, sparse_frac=0.02, heavy_rows=1, device=gpu, seed=3)
+    good_rows = lay["rows"].clone()
+    x = torch.randn(1, 256, device=gpu, dtype=torch.float16)
+    mod = quant.QuantLinearLUT.from_operands(lay)
+    mod.__class__ = quant.QuantLinearLUTFused
+    mod(x)  # consistent: fine
+    bad = dict(lay)
+    bad["rows"] = good_rows.clone()
+    bad["rows"][5] = bad["rows"][6] + 1  # not non-decreasing
+    mod2 = quant.QuantLinearLUT.from_operands(bad)
+    mod2.__class__ = quant.QuantLinearLUTFused
+    with pytest.raises(ValueError, match="inconsistent CSR"):
+        mod2(x)
+    # the C ABI's debug option, through an operator name
+    y = torch.zeros(128, device=gpu)
+    qc.vecquant4matmul_spmv_nuq_perchannel(good_rows, lay["cols"], lay["vals"], x.float().reshape(-1), y, 128, lay["qweight"], lay["lookup_table"])
+    _lib.set_option("validate_csr", 1)
+    try:
+        qc.vecquant4matmul_spmv_nuq_perchannel(good_rows, lay["cols"], lay["vals"], x.float().reshape(-1), y, 128, lay["qweight"], lay["lookup_table"])
+        with pytest.raises(ValueError, match="sparse"):
+            qc.vecquant4matmul_spmv_nuq_perchannel(bad["rows"], lay["cols"], lay["vals"], x.float().reshape(-1), y, 128, lay["qweight"], lay["lookup_table"])
+        short = good_rows.clone()
+        short[-1] -= 1  # rows[N] != nnz
+        with pytest.raises(ValueError, match="sparse"):
+            qc.vecquant4matmul_spmv_nuq_perchannel(short, lay["cols"], lay["vals"], x.float().reshape(-1), y, 128, lay["qweight"], lay["lookup_table"])
+    finally:
+        _lib.set_option("validate_csr", 0)
+    torch.cuda.synchronize()
