@@ -239,7 +239,8 @@ int sqllm_vecquant4matmul_spmv_balanced_nuq_perchannel(
 int sqllm_abi_version(void);
 const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hipError_t values */
 
-/* Launch-geometry knobs (for measurement sweeps; defaults are chosen per shape):
+/* Launch-geometry knobs (for measurement sweeps; defaults are chosen per shape).  Options are kept
+ * PER DEVICE: a set / get applies to the calling thread's current HIP device.
  *   "target_wgs"      dense workgroups to aim for (default 0 = 1 x CU count for layers <= 12 MB,
  *                     3 x CU count above)
  *   "groups_per_wave" force the K units each wave walks (default 0 = derived from target_wgs)

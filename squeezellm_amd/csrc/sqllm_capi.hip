@@ -13,18 +13,35 @@
 
 namespace {
 
-std::atomic<int> g_target_wgs{0};
-std::atomic<int> g_groups_per_wave{0};
-std::atomic<int> g_cu_count{0};
-std::atomic<int> g_ablate{0};
-std::atomic<int> g_sparse_last{0};
-std::atomic<int> g_ablate_csr{0};
-std::atomic<int> g_mfma_min_batch{9};
-std::atomic<int> g_validate_csr{0};    // debug: check rows[] on the device before every launch that carries a CSR term  // *_batched ops with at least this many rows take the matrix-core kernel
-std::atomic<void*> g_timeline{nullptr};  // measurement build: per-workgroup timestamp buffer
+// Tuning knobs and debug switches are PER DEVICE (a set / get applies to the calling thread's current
+// HIP device; slot 0 when no device is usable, e.g. in GPU-less planning tests): several GPUs driven
+// from one process, or threads on different devices, do not steer each other's launches.
+struct Knobs {
+  std::atomic<int> target_wgs{0};
+  std::atomic<int> groups_per_wave{0};
+  std::atomic<int> cu_count{0};
+  std::atomic<int> ablate{0};
+  std::atomic<int> sparse_last{0};
+  std::atomic<int> ablate_csr{0};
+  std::atomic<int> mfma_min_batch{9};  // *_batched ops with at least this many rows take the matrix-core kernel
+  std::atomic<int> validate_csr{0};    // debug: check rows[] on the device before every launch that carries a CSR term
+  std::atomic<void*> timeline{nullptr};  // measurement build: per-workgroup timestamp buffer
+};
+constexpr int kMaxDevices = 32;
+Knobs g_knobs[kMaxDevices];
+
+Knobs& knobs() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();  // no usable device: not an error of the call being served
+    dev = 0;
+  }
+  if (dev < 0 || dev >= kMaxDevices) dev = 0;
+  return g_knobs[dev];
+}
 
 int cu_count() {
-  int c = g_cu_count.load(std::memory_order_relaxed);
+  int c = knobs().cu_count.load(std::memory_order_relaxed);
   if (c > 0) return c;
   int dev = 0;
   hipDeviceProp_t prop;
@@ -33,7 +50,7 @@ int cu_count() {
     c = prop.multiProcessorCount;
   else
     c = 256;  // MI355X
-  g_cu_count.store(c, std::memory_order_relaxed);
+  knobs().cu_count.store(c, std::memory_order_relaxed);
   return c;
 }
 
@@ -61,7 +78,7 @@ int validate(const sqllm_op* op) {
 
 // option "validate_csr": a value check of rows[] on the device (blocks the host; debugging aid)
 int validate_csr_values(const sqllm_op* op, sqllm_stream_t stream) {
-  if (!g_validate_csr.load(std::memory_order_relaxed) || !op->rows || op->nnz <= 0) return SQLLM_OK;
+  if (!knobs().validate_csr.load(std::memory_order_relaxed) || !op->rows || op->nnz <= 0) return SQLLM_OK;
   int bad = 0;
   hipError_t e = sqllm::check_csr(op->rows, op->N, op->nnz, static_cast<hipStream_t>(stream), &bad);
   if (e != hipSuccess) return static_cast<int>(e);
@@ -81,9 +98,9 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1)
   gm->col_tiles = (op->N + sqllm::kTileN - 1) / sqllm::kTileN;
   gm->units_total = op->K / kK;
   const int step = sqllm::kWaves * 4;  // units one workgroup step covers
-  int upw = g_groups_per_wave.load(std::memory_order_relaxed) * sqllm::kWaves;
+  int upw = knobs().groups_per_wave.load(std::memory_order_relaxed) * sqllm::kWaves;
   if (upw <= 0) {
-    int target = g_target_wgs.load(std::memory_order_relaxed);
+    int target = knobs().target_wgs.load(std::memory_order_relaxed);
     if (target <= 0) {
       // measured on MI355X (tools/sweep.py, bench.py): an op under ~12 MB of packed weights runs
       // best with one 8-wave workgroup per CU when it shares its launch with others (q/k/v) and
@@ -110,10 +127,10 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1)
   gm->topx_blocks = gm->topX ? (op->K + sqllm::kTopxRows - 1) / sqllm::kTopxRows : 0;
   // dense blocks start at a multiple of 8 so that (dense id % 8) is the XCD of the workgroup
   gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
-  gm->sparse_last = g_sparse_last.load(std::memory_order_relaxed);
+  gm->sparse_last = knobs().sparse_last.load(std::memory_order_relaxed);
   if (gm->sparse_last) gm->dense_block0 = gm->csr_blocks + gm->topx_blocks;  // grid = dense + sparse
 #ifdef SQLLM_ABLATION_BUILD
-  gm->sparse_last |= g_ablate_csr.load(std::memory_order_relaxed) << 1;  // CSR-role ablation bits ride along
+  gm->sparse_last |= knobs().ablate_csr.load(std::memory_order_relaxed) << 1;  // CSR-role ablation bits ride along
 #endif
 }
 
@@ -126,9 +143,9 @@ void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm) {
   const int mb = sqllm::mfma_row_blocks(gm->batch);
   const int grid_y = (gm->batch + 16 * mb - 1) / (16 * mb);
   const int step = sqllm::kWaves * 4;
-  int upw = g_groups_per_wave.load(std::memory_order_relaxed) * sqllm::kWaves;
+  int upw = knobs().groups_per_wave.load(std::memory_order_relaxed) * sqllm::kWaves;
   if (upw <= 0) {
-    int target = g_target_wgs.load(std::memory_order_relaxed);
+    int target = knobs().target_wgs.load(std::memory_order_relaxed);
     if (target <= 0) target = 2 * cu_count();
     int slices = (target + gm->col_tiles * grid_y - 1) / (gm->col_tiles * grid_y);
     if (slices < 1) slices = 1;
@@ -144,7 +161,7 @@ void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm) {
 }
 
 bool takes_mfma_path(const sqllm_op* op) {
-  return op->batch >= 1 && op->batch >= g_mfma_min_batch.load(std::memory_order_relaxed);
+  return op->batch >= 1 && op->batch >= knobs().mfma_min_batch.load(std::memory_order_relaxed);
 }
 
 }  // namespace
@@ -172,31 +189,31 @@ const char* sqllm_error_string(int code) {
 
 #ifdef SQLLM_ABLATION_BUILD
 // measurement build only (not in the header): device buffer of 8 x u64 per workgroup of the next launches
-void sqllm_debug_set_timeline(void* buf) { g_timeline.store(buf); }
+void sqllm_debug_set_timeline(void* buf) { knobs().timeline.store(buf); }
 #endif
 
 int sqllm_set_option(const char* name, int value) {
   if (!name || value < 0) return SQLLM_E_OPTION;
-  if (!strcmp(name, "target_wgs")) { g_target_wgs.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "groups_per_wave")) { g_groups_per_wave.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "sparse_last")) { g_sparse_last.store(value ? 1 : 0); return SQLLM_OK; }
-  if (!strcmp(name, "cu_count")) { g_cu_count.store(value); return SQLLM_OK; }  // for GPU-less planning tests
-  if (!strcmp(name, "mfma_min_batch")) { g_mfma_min_batch.store(value < 1 ? 1 : value); return SQLLM_OK; }
-  if (!strcmp(name, "validate_csr")) { g_validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
+  if (!strcmp(name, "target_wgs")) { knobs().target_wgs.store(value); return SQLLM_OK; }
+  if (!strcmp(name, "groups_per_wave")) { knobs().groups_per_wave.store(value); return SQLLM_OK; }
+  if (!strcmp(name, "sparse_last")) { knobs().sparse_last.store(value ? 1 : 0); return SQLLM_OK; }
+  if (!strcmp(name, "cu_count")) { knobs().cu_count.store(value); return SQLLM_OK; }  // for GPU-less planning tests
+  if (!strcmp(name, "mfma_min_batch")) { knobs().mfma_min_batch.store(value < 1 ? 1 : value); return SQLLM_OK; }
+  if (!strcmp(name, "validate_csr")) { knobs().validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
 #ifdef SQLLM_ABLATION_BUILD
-  if (!strcmp(name, "ablate")) { g_ablate.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "ablate_csr")) { g_ablate_csr.store(value); return SQLLM_OK; }
+  if (!strcmp(name, "ablate")) { knobs().ablate.store(value); return SQLLM_OK; }
+  if (!strcmp(name, "ablate_csr")) { knobs().ablate_csr.store(value); return SQLLM_OK; }
 #endif
   return SQLLM_E_OPTION;
 }
 
 int sqllm_get_option(const char* name, int* value) {
   if (!name || !value) return SQLLM_E_OPTION;
-  if (!strcmp(name, "target_wgs")) { *value = g_target_wgs.load(); return SQLLM_OK; }
-  if (!strcmp(name, "groups_per_wave")) { *value = g_groups_per_wave.load(); return SQLLM_OK; }
-  if (!strcmp(name, "cu_count")) { *value = g_cu_count.load(); return SQLLM_OK; }
-  if (!strcmp(name, "mfma_min_batch")) { *value = g_mfma_min_batch.load(); return SQLLM_OK; }
-  if (!strcmp(name, "validate_csr")) { *value = g_validate_csr.load(); return SQLLM_OK; }
+  if (!strcmp(name, "target_wgs")) { *value = knobs().target_wgs.load(); return SQLLM_OK; }
+  if (!strcmp(name, "groups_per_wave")) { *value = knobs().groups_per_wave.load(); return SQLLM_OK; }
+  if (!strcmp(name, "cu_count")) { *value = knobs().cu_count.load(); return SQLLM_OK; }
+  if (!strcmp(name, "mfma_min_batch")) { *value = knobs().mfma_min_batch.load(); return SQLLM_OK; }
+  if (!strcmp(name, "validate_csr")) { *value = knobs().validate_csr.load(); return SQLLM_OK; }
   return SQLLM_E_OPTION;
 }
 
@@ -282,7 +299,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
   a.linear = lin != nullptr;
   a.ev_start = e0;
   a.ev_stop = e1;
-  a.ablate = g_ablate.load(std::memory_order_relaxed);
+  a.ablate = knobs().ablate.load(std::memory_order_relaxed);
   a.x = ops[0].vec;
   a.ga.n_seg = n;
   int block = 0;
@@ -307,7 +324,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     sg.bias = nullptr;
     sg.out16 = nullptr;
 #ifdef SQLLM_ABLATION_BUILD
-    if (!lin) sg.bias = static_cast<const float*>(g_timeline.load(std::memory_order_relaxed));
+    if (!lin) sg.bias = static_cast<const float*>(knobs().timeline.load(std::memory_order_relaxed));
 #endif
     make_plan(op, &sg.gm, n);
     if (lin) {

@@ -33,9 +33,9 @@ def test_partition_layers():
 HIDDEN, LAYERS, TICKS = 64, 4, 8
 
 
-def _make_layers():
-    """A tiny 'decoder stack': LAYERS square quantised linears with bias-free hybrid operands."""
-    return [H.make_case(4 if i % 2 else 3, HIDDEN, HIDDEN, sparse=0.05, topX=2, seed=100 + i) for i in range(LAYERS)]
+def _make_layers(n_layers=LAYERS):
+    """A tiny 'decoder stack': n_layers square quantised linears with bias-free hybrid operands."""
+    return [H.make_case(4 if i % 2 else 3, HIDDEN, HIDDEN, sparse=0.05, topX=2, seed=100 + i) for i in range(n_layers)]
 
 
 def _stage_fn(layers):
@@ -54,10 +54,10 @@ def _h0(r):
     return torch.from_numpy(np.random.default_rng(500 + r).normal(size=HIDDEN)).float()
 
 
-def _reference_ring(world):
+def _reference_ring(world, n_layers=LAYERS):
     """Single-process emulation of the ring schedule for `world` stages."""
-    layers = _make_layers()
-    parts = sharding.partition_layers(LAYERS, world)
+    layers = _make_layers(n_layers)
+    parts = sharding.partition_layers(n_layers, world)
     stages = [_stage_fn(layers[a:b]) for a, b in parts]
     h_in = [_h0(r) for r in range(world)]
     outs = None
@@ -67,11 +67,11 @@ def _reference_ring(world):
     return torch.stack(outs)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_layers=LAYERS):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    layers = _make_layers()
-    a, b = sharding.partition_layers(LAYERS, world)[rank]
+    layers = _make_layers(n_layers)
+    a, b = sharding.partition_layers(n_layers, world)[rank]
     pipe = sharding.RingPipeline(_stage_fn(layers[a:b]), HIDDEN, rank=rank, world_size=world, device="cpu",
                                  dtype=torch.float32, h0=_h0(rank))
     out = None
@@ -82,19 +82,22 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
-def test_ring_pipeline_gloo_matches_single_process(world):
+# world 2: even split; world 4 over 6 layers: uneven ranges (2, 2, 1, 1); world 4 over 3 layers: the last
+# rank owns NO layer and passes the hidden state through
+@pytest.mark.parametrize("world,n_layers", [(2, LAYERS), (4, 6), (4, 3)])
+def test_ring_pipeline_gloo_matches_single_process(world, n_layers):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29500 + (os.getpid() % 2000) + 7 * world + n_layers
+    assert [b - a for a, b in sharding.partition_layers(n_layers, world)] == {(2, 4): [2, 2], (4, 6): [2, 2, 1, 1], (4, 3): [1, 1, 1, 0]}[(world, n_layers)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n_layers)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    want = _reference_ring(world).numpy()
+    want = _reference_ring(world, n_layers).numpy()
     for rank, out, buf in res:
         assert np.allclose(out, want[rank], rtol=1e-5, atol=1e-6)
         assert np.allclose(buf, want, rtol=1e-5, atol=1e-6)  # everyone gathered everyone's output
