@@ -52,6 +52,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         extra.append("-DSQLLM_PAIR3=" + str(int(os.environ["SQLLM_PAIR3"])))
     if os.environ.get("SQLLM_HALF_STAGES"):  # measurement builds: 0 = whole-stage decode (32 live lookups)
         extra.append("-DSQLLM_HALF_STAGES=" + str(int(os.environ["SQLLM_HALF_STAGES"])))
+    if os.environ.get("SQLLM_PAIR3_NOCONFLICT"):  # measurement builds (wrong results): 3-bit pair lookups without bank conflicts
+        extra.append("-DSQLLM_PAIR3_NOCONFLICT=" + str(int(os.environ["SQLLM_PAIR3_NOCONFLICT"])))
     if os.environ.get("SQLLM_PIPE"):  # measurement builds: software-pipelined 4-bit chunk decode
         extra.append("-DSQLLM_PIPE=" + str(int(os.environ["SQLLM_PIPE"])))
     if os.environ.get("SQLLM_SCHED_PATTERN"):  # measurement builds: fixed decode-stage schedules

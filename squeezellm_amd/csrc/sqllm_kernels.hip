@@ -60,6 +60,12 @@
 #ifndef SQLLM_PAIR3
 #define SQLLM_PAIR3 1  // 0 (measurement builds): 3-bit batch-1 decode with one lookup per weight
 #endif
+#ifndef SQLLM_PAIR3_NOCONFLICT
+// 1 (measurement builds, WRONG RESULTS): the 3-bit pair lookups take their entry's parity from the
+// lane row instead of from the data, so the two lane rows of a half-wave can never meet on a bank --
+// same instruction count, zero bank conflicts: the A/B that prices the conflicts of the real layout
+#define SQLLM_PAIR3_NOCONFLICT 0
+#endif
 #ifndef SQLLM_HALF_STAGES
 #define SQLLM_HALF_STAGES 1  // 0 (measurement builds): whole-stage decode, 32 live lookups
 #endif
@@ -485,7 +491,11 @@ __device__ __forceinline__ uint32_t field6_x128(uint32_t t0, uint32_t t1, uint32
     const uint32_t hi = (w == 0) ? t1 : t2;
     f = __builtin_amdgcn_alignbit(hi, lo, o) << 7;
   }
+#if SQLLM_PAIR3_NOCONFLICT
+  return f & 0x1F00u;  // measurement build: entry parity comes from the lane row (see tb[] in dense_role)
+#else
   return f & 0x1F80u;
+#endif
 }
 
 __device__ __forceinline__ f32x2 lds_read_f32x2(uint32_t byte_addr) {
@@ -924,7 +934,7 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   const uint32_t lane_off = 4 * (i16 + 16 * (grp & 1));  // 4-bit: dword slot inside a 128-byte half row
   uint32_t tb[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) tb[j] = PAIR ? j * 8192 + 8 * i16 : j * SUBB + 4 * (i16 + 16 * (grp & 1));
+  for (int j = 0; j < 4; ++j) tb[j] = PAIR ? j * 8192 + 8 * i16 + (SQLLM_PAIR3_NOCONFLICT ? 128 * (grp & 1) : 0) : j * SUBB + 4 * (i16 + 16 * (grp & 1));
   f32x2 accp[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};  // PAIR: (even k, odd k) per column
 
   __syncthreads();  // codebooks visible
