@@ -66,6 +66,12 @@
 // same instruction count, zero bank conflicts: the A/B that prices the conflicts of the real layout
 #define SQLLM_PAIR3_NOCONFLICT 0
 #endif
+#ifndef SQLLM_MFMA_VAR
+#define SQLLM_MFMA_VAR 0
+#endif
+#ifndef SQLLM_MFMA_FAKE
+#define SQLLM_MFMA_FAKE 0  // 1 (measurement builds, wrong results): the wide-batch kernel without its matrix instructions
+#endif
 #ifndef SQLLM_HALF_STAGES
 #define SQLLM_HALF_STAGES 1  // 0 (measurement builds): whole-stage decode, 32 live lookups
 #endif
@@ -1512,24 +1518,45 @@ __device__ __forceinline__ void dense_role_mfma(const float* __restrict__ x, con
   auto phase = [&](const float (&v)[4][8], const f32x4 (&dx)[XL], int g) {
     const bool live = group_unit(g, xkq) < u_end;
 #pragma unroll
-    for (int j = 0; j < XL; ++j) *reinterpret_cast<f32x4*>(xt_w + 8 * j * kXtStride) = live ? dx[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < XL; ++j)
+      if (!(SQLLM_MFMA_VAR & 8)) *reinterpret_cast<f32x4*>(xt_w + 8 * j * kXtStride) = live ? dx[j] : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 alo[MB], ahi[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      alo[mb] = *reinterpret_cast<const f32x4*>(xt_r + 16 * mb * kXtStride);
-      ahi[mb] = *reinterpret_cast<const f32x4*>(xt_r + 16 * mb * kXtStride + 4);
+      if constexpr (SQLLM_MFMA_VAR & 8) {  // measurement: A operands straight from the loaded registers, no LDS round trip
+        alo[mb] = dx[0];
+        ahi[mb] = dx[XL - 1];
+      } else {
+        alo[mb] = *reinterpret_cast<const f32x4*>(xt_r + 16 * mb * kXtStride);
+        ahi[mb] = *reinterpret_cast<const f32x4*>(xt_r + 16 * mb * kXtStride + 4);
+      }
     }
+    if (SQLLM_MFMA_VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s2 = 0; s2 < 8; ++s2)
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const float a = s2 < 4 ? alo[mb][s2 & 3] : ahi[mb][s2 & 3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v[j][s2], acc[mb][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+#if SQLLM_MFMA_FAKE
+          acc[mb][j].x = __builtin_fmaf(a, v[j][s2], acc[mb][j].x);  // measurement build: everything but the matrix pipe
+#else
+          acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v[j][s2], acc[mb][j], 0, 0, 0);
+#endif
+        }
       }
+    if (SQLLM_MFMA_VAR & 1) __builtin_amdgcn_s_setprio(0);
   };
   auto lookups = [&](const u32x4 (&t)[R], auto ph_tag, float (&v)[4][8]) {
     constexpr int PH = decltype(ph_tag)::value;
+    if constexpr (SQLLM_MFMA_VAR & 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[j][i] = __builtin_bit_cast(float, t[0].x ^ (uint32_t)(j * 8 + i));
+      return;
+    }
     if constexpr (BITS == 4) {
       const uint32_t w4[4] = {t[0].x, t[0].y, t[0].z, t[0].w};
 #pragma unroll
@@ -1573,29 +1600,29 @@ __device__ __forceinline__ void dense_role_mfma(const float* __restrict__ x, con
     float v[4][8];
     if constexpr (NPH == 1) {
       load_x(g + 1, 0, xn);
-      __builtin_amdgcn_sched_barrier(0);
+      if (!(SQLLM_MFMA_VAR & 2)) __builtin_amdgcn_sched_barrier(0);
       lookups(w, P0{}, v);
       phase(v, xcur, g);
     } else {
       f32x4 xo[XL];
       load_x(g, 1, xo);
-      __builtin_amdgcn_sched_barrier(0);
+      if (!(SQLLM_MFMA_VAR & 2)) __builtin_amdgcn_sched_barrier(0);
       lookups(w, P0{}, v);
       phase(v, xcur, g);
       load_x(g, 2, xcur);
-      __builtin_amdgcn_sched_barrier(0);
+      if (!(SQLLM_MFMA_VAR & 2)) __builtin_amdgcn_sched_barrier(0);
       lookups(w, P1{}, v);
       phase(v, xo, g);
       load_x(g, 3, xo);
-      __builtin_amdgcn_sched_barrier(0);
+      if (!(SQLLM_MFMA_VAR & 2)) __builtin_amdgcn_sched_barrier(0);
       lookups(w, P2{}, v);
       phase(v, xcur, g);
       load_x(g + 1, 0, xn);
-      __builtin_amdgcn_sched_barrier(0);
+      if (!(SQLLM_MFMA_VAR & 2)) __builtin_amdgcn_sched_barrier(0);
       lookups(w, P3{}, v);
       phase(v, xo, g);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if (!(SQLLM_MFMA_VAR & 2)) __builtin_amdgcn_sched_barrier(0);
   };
   // two register sets swap roles (a copy would make the compiler wait for the loads in flight);
   // groups past the wave's last one re-read valid memory and multiply by zeroed vec pieces
@@ -1646,10 +1673,13 @@ sqllm_fused_batched(const float* x, const GroupArgs ga) {
     dense_role_mfma<BITS, MB, WAVES>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, d,
                                      gm.col_tiles, gm.units_total, gm.units_per_wg, lds);
   } else if (sp >= 0 && sp < gm.csr_blocks) {
-    for (int bb = 0; bb < rows_here; bb += kMaxBatchTile) {
+    // the CSR chunk takes the pass's rows 16 (one row block) or 32 at a time: every group of rows costs
+    // the chunk a zero / gather / flush round with its barriers
+    constexpr int CBT = MB == 1 ? 16 : 32;
+    for (int bb = 0; bb < rows_here; bb += CBT) {
       if (bb) __syncthreads();
-      csr_role<T, kMaxBatchTile, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, m0 + bb,
-                                               rows_here - bb < kMaxBatchTile ? rows_here - bb : kMaxBatchTile, sp, lds, nullptr, 0);
+      csr_role<T, CBT, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, m0 + bb,
+                                     rows_here - bb < CBT ? rows_here - bb : CBT, sp, lds, nullptr, 0);
     }
   } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
     topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, m0, rows_here, sp - gm.csr_blocks, lds);

@@ -24,17 +24,18 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 enum Kind { K_PERM = 0, K_FMA, K_FMAC_SGPR, K_PKFMA, K_PKFMA_SGPR, K_ANDOR, K_FMAC_DPP, K_LDS32, K_LDS64, K_LDS128,
-            K_MIX4, K_MIX4_FMA, K_MIX3, K_LDSW64, K_LDSW2x32, K_OVL_B64, K_OVL_B32, K_MFMA16, K_MFMA4, K_MFMA32, K_N };
+            K_MIX4, K_MIX4_FMA, K_MIX3, K_LDSW64, K_LDSW2x32, K_OVL_B64, K_OVL_B32, K_MFMA16, K_MFMA4, K_MFMA32, K_MFMA16V, K_N };
 static const char* kNames[K_N] = {
     "v_perm_b32", "v_fma_f32 (vgpr)", "v_fmac_f32 (sgpr x)", "v_pk_fma_f32 (vgpr)", "v_pk_fma_f32 (sgpr pair x)",
     "v_and_or_b32", "v_fmac_f32 dpp row_newbcast", "ds_read_b32", "ds_read_b64", "ds_read_b128",
     "mix w4 pair: 1 perm + 1 ds_read_b64 + 1 pk_fma(sgpr)", "mix w4 pair: 1 perm + 1 ds_read_b64 + 2 fmac(sgpr)",
     "mix w3 pair: 2 valu addr + 1 ds_read_b64 + 1 pk_fma(sgpr)", "ds_write_b64", "ds_write2_b32",
     "overlap: 64 v_perm + 32 ds_read_b64 (independent, one wait per block)", "overlap: 64 v_perm + 32 ds_read_b32 (independent, one wait per block)",
-    "v_mfma_f32_16x16x4_f32 (4 independent accumulators)", "v_mfma_f32_4x4x1_16b_f32 (4 independent accumulators)", "v_mfma_f32_32x32x2_f32 (2 independent accumulators)"};
+    "v_mfma_f32_16x16x4_f32 (4 independent accumulators)", "v_mfma_f32_4x4x1_16b_f32 (4 independent accumulators)", "v_mfma_f32_32x32x2_f32 (2 independent accumulators)",
+    "v_mfma_f32_16x16x4_f32, 8 different A / B registers, RANDOM operand values"};
 // instructions per block (per loop iteration), and which of them are VALU / LDS
-static const int kValuPerBlock[K_N] = {64, 64, 64, 64, 64, 64, 64, 0, 0, 0, 32, 48, 48, 0, 0, 64, 64, 32, 32, 16};
-static const int kLdsPerBlock[K_N] = {0, 0, 0, 0, 0, 0, 0, 64, 64, 64, 16, 16, 16, 64, 64, 32, 32, 0, 0, 0};
+static const int kValuPerBlock[K_N] = {64, 64, 64, 64, 64, 64, 64, 0, 0, 0, 32, 48, 48, 0, 0, 64, 64, 32, 32, 16, 32};
+static const int kLdsPerBlock[K_N] = {0, 0, 0, 0, 0, 0, 0, 64, 64, 64, 16, 16, 16, 64, 64, 32, 32, 0, 0, 0, 0};
 
 #define REP2(x) x x
 #define REP4(x) REP2(x) REP2(x)
@@ -68,6 +69,15 @@ __global__ void __launch_bounds__(1024) k_rate(unsigned long long* out, int iter
   f32x16 md0, md1;
 #pragma unroll
   for (int e = 0; e < 16; ++e) { md0[e] = f0 + e; md1[e] = f1 - e; }
+  if constexpr (KIND == K_MFMA16V) {  // random operand bits (cf. K_MFMA16: constants): data-dependent power
+    auto rnd = [&](unsigned k) { unsigned h = (tid * 2654435761u) ^ (k * 40503u + blockIdx.x * 97u); h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+                                 return __builtin_bit_cast(float, (h & 0x007FFFFFu) | 0x3C800000u) * ((h >> 31) ? -1.f : 1.f); };
+    f0 = rnd(0); f1 = rnd(1); f2 = rnd(2); f3 = rnd(3); f4 = rnd(4); f5 = rnd(5); f6 = rnd(6); f7 = rnd(7);
+    a0 = __builtin_bit_cast(unsigned, rnd(8)); a1 = __builtin_bit_cast(unsigned, rnd(9)); a2 = __builtin_bit_cast(unsigned, rnd(10)); a3 = __builtin_bit_cast(unsigned, rnd(11));
+    a4 = __builtin_bit_cast(unsigned, rnd(12)); a5 = __builtin_bit_cast(unsigned, rnd(13)); a6 = __builtin_bit_cast(unsigned, rnd(14)); a7 = __builtin_bit_cast(unsigned, rnd(15));
+    mc0 = f32x4{rnd(16), rnd(17), rnd(18), rnd(19)}; mc1 = f32x4{rnd(20), rnd(21), rnd(22), rnd(23)};
+    mc2 = f32x4{rnd(24), rnd(25), rnd(26), rnd(27)}; mc3 = f32x4{rnd(28), rnd(29), rnd(30), rnd(31)};
+  }
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   for (int it = 0; it < iters; ++it) {
@@ -157,6 +167,12 @@ __global__ void __launch_bounds__(1024) k_rate(unsigned long long* out, int iter
     } else if constexpr (KIND == K_MFMA32) {
       asm volatile(REP8("v_mfma_f32_32x32x2_f32 %0, %2, %3, %0\n v_mfma_f32_32x32x2_f32 %1, %2, %4, %1\n")
                    : "+v"(md0), "+v"(md1) : "v"(m), "v"(f0), "v"(f1));
+    } else if constexpr (KIND == K_MFMA16V) {
+      asm volatile(REP4("v_mfma_f32_16x16x4_f32 %0, %4, %12, %0\n v_mfma_f32_16x16x4_f32 %1, %4, %13, %1\n v_mfma_f32_16x16x4_f32 %2, %4, %14, %2\n v_mfma_f32_16x16x4_f32 %3, %4, %15, %3\n"
+                        "v_mfma_f32_16x16x4_f32 %0, %5, %16, %0\n v_mfma_f32_16x16x4_f32 %1, %5, %17, %1\n v_mfma_f32_16x16x4_f32 %2, %5, %18, %2\n v_mfma_f32_16x16x4_f32 %3, %5, %19, %3\n")
+                   : "+v"(mc0), "+v"(mc1), "+v"(mc2), "+v"(mc3)
+                   : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4), "v"(f5), "v"(f6), "v"(f7),
+                     "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
     } else if constexpr (KIND == K_MIX3) {
       asm volatile(REP4(
                        "v_lshrrev_b32 %8, 3, %4\n v_and_or_b32 %8, %8, %7, %6\n ds_read_b64 %0, %8\n v_lshrrev_b32 %9, 9, %5\n v_and_or_b32 %9, %9, %7, %6\n ds_read_b64 %1, %9\n"
@@ -234,5 +250,6 @@ int main() {
   run<K_MFMA16>(dout, cus);
   run<K_MFMA4>(dout, cus);
   run<K_MFMA32>(dout, cus);
+  run<K_MFMA16V>(dout, cus);
   return 0;
 }
