@@ -24,7 +24,7 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 enum Kind { K_PERM = 0, K_FMA, K_FMAC_SGPR, K_PKFMA, K_PKFMA_SGPR, K_ANDOR, K_FMAC_DPP, K_LDS32, K_LDS64, K_LDS128,
-            K_MIX4, K_MIX4_FMA, K_MIX3, K_LDSW64, K_LDSW2x32, K_OVL_B64, K_OVL_B32, K_MFMA16, K_MFMA4, K_MFMA32, K_MFMA16V, K_N };
+            K_MIX4, K_MIX4_FMA, K_MIX3, K_LDSW64, K_LDSW2x32, K_OVL_B64, K_OVL_B32, K_MFMA16, K_MFMA4, K_MFMA32, K_MFMA16V, K_LDSADDF, K_LDSADDU, K_N };
 static const char* kNames[K_N] = {
     "v_perm_b32", "v_fma_f32 (vgpr)", "v_fmac_f32 (sgpr x)", "v_pk_fma_f32 (vgpr)", "v_pk_fma_f32 (sgpr pair x)",
     "v_and_or_b32", "v_fmac_f32 dpp row_newbcast", "ds_read_b32", "ds_read_b64", "ds_read_b128",
@@ -32,10 +32,11 @@ static const char* kNames[K_N] = {
     "mix w3 pair: 2 valu addr + 1 ds_read_b64 + 1 pk_fma(sgpr)", "ds_write_b64", "ds_write2_b32",
     "overlap: 64 v_perm + 32 ds_read_b64 (independent, one wait per block)", "overlap: 64 v_perm + 32 ds_read_b32 (independent, one wait per block)",
     "v_mfma_f32_16x16x4_f32 (4 independent accumulators)", "v_mfma_f32_4x4x1_16b_f32 (4 independent accumulators)", "v_mfma_f32_32x32x2_f32 (2 independent accumulators)",
-    "v_mfma_f32_16x16x4_f32, 8 different A / B registers, RANDOM operand values"};
+    "v_mfma_f32_16x16x4_f32, 8 different A / B registers, RANDOM operand values",
+    "ds_add_f32 (64 lanes, 64 different addresses)", "ds_add_u32 (64 lanes, 64 different addresses)"};
 // instructions per block (per loop iteration), and which of them are VALU / LDS
-static const int kValuPerBlock[K_N] = {64, 64, 64, 64, 64, 64, 64, 0, 0, 0, 32, 48, 48, 0, 0, 64, 64, 32, 32, 16, 32};
-static const int kLdsPerBlock[K_N] = {0, 0, 0, 0, 0, 0, 0, 64, 64, 64, 16, 16, 16, 64, 64, 32, 32, 0, 0, 0, 0};
+static const int kValuPerBlock[K_N] = {64, 64, 64, 64, 64, 64, 64, 0, 0, 0, 32, 48, 48, 0, 0, 64, 64, 32, 32, 16, 32, 0, 0};
+static const int kLdsPerBlock[K_N] = {0, 0, 0, 0, 0, 0, 0, 64, 64, 64, 16, 16, 16, 64, 64, 32, 32, 0, 0, 0, 0, 16, 16};
 
 #define REP2(x) x x
 #define REP4(x) REP2(x) REP2(x)
@@ -173,6 +174,14 @@ __global__ void __launch_bounds__(1024) k_rate(unsigned long long* out, int iter
                    : "+v"(mc0), "+v"(mc1), "+v"(mc2), "+v"(mc3)
                    : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4), "v"(f5), "v"(f6), "v"(f7),
                      "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+    } else if constexpr (KIND == K_LDSADDF) {
+      asm volatile(REP4("ds_add_f32 %0, %1 offset:256\n ds_add_f32 %0, %2 offset:2816\n ds_add_f32 %0, %3 offset:1536\n ds_add_f32 %0, %4 offset:3584\n")
+                   "s_waitcnt lgkmcnt(0)\n"
+                   :: "v"(base32), "v"(f0), "v"(f1), "v"(f2), "v"(f3) : "memory");
+    } else if constexpr (KIND == K_LDSADDU) {
+      asm volatile(REP4("ds_add_u32 %0, %1 offset:256\n ds_add_u32 %0, %2 offset:2816\n ds_add_u32 %0, %3 offset:1536\n ds_add_u32 %0, %4 offset:3584\n")
+                   "s_waitcnt lgkmcnt(0)\n"
+                   :: "v"(base32), "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
     } else if constexpr (KIND == K_MIX3) {
       asm volatile(REP4(
                        "v_lshrrev_b32 %8, 3, %4\n v_and_or_b32 %8, %8, %7, %6\n ds_read_b64 %0, %8\n v_lshrrev_b32 %9, 9, %5\n v_and_or_b32 %9, %9, %7, %6\n ds_read_b64 %1, %9\n"
@@ -251,5 +260,7 @@ int main() {
   run<K_MFMA4>(dout, cus);
   run<K_MFMA32>(dout, cus);
   run<K_MFMA16V>(dout, cus);
+  run<K_LDSADDF>(dout, cus);
+  run<K_LDSADDU>(dout, cus);
   return 0;
 }

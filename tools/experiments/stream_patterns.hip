@@ -6,6 +6,8 @@
 //   pattern 1  strip, 256 columns wide (1 KiB), dwordx4 per lane; waves interleave rows
 //   pattern 2  linear: each workgroup reads one contiguous range, dwordx4 per lane
 //   pattern 3  strip 64 wide, but a wave owns a CONTIGUOUS block of rows (not interleaved)
+//   pattern 4  pattern 0 through buffer_load_dword (a descriptor over the matrix) instead of global_load_dword
+//   pattern 5  pattern 4 with a ROLLING ring: two loads issued per two words consumed (D words in flight)
 // Workgroups take contiguous ranges of the flattened (strip, row) space (as the v2 kernel does).
 // Every variant: T waves per workgroup, D loads in flight per wave (issue D, consume D, repeat, two
 // register sets so that D..2D are outstanding), grid = G workgroups per CU.
@@ -86,6 +88,60 @@ __global__ void __launch_bounds__(T * 64) k_stream(const uint32_t* __restrict__ 
   if (acc == 0x12345678u) y[0] = 1.f;
 }
 
+template <int PATTERN, int T, int D>
+__global__ void __launch_bounds__(T * 64) k_stream_buf(const uint32_t* __restrict__ q, int rows, int N, int units_per_wg, float* y) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint32_t acc = 0;
+  const int n_strips = (N + 63) / 64;
+  const unsigned total = (unsigned)n_strips * rows;
+  unsigned g = blockIdx.x * (unsigned)units_per_wg, g_end = g + units_per_wg;
+  if (g_end > total) g_end = total;
+  const uint32_t row_bytes = 4u * N;
+  while (g < g_end) {
+    const unsigned strip = g / rows;
+    const int r0 = g - strip * rows;
+    int r1 = rows;
+    if ((unsigned)(r1 - r0) > g_end - g) r1 = r0 + (g_end - g);
+    g += r1 - r0;
+    int c = strip * 64 + lane;
+    if (c > N - 1) c = N - 1;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(q), 0, (uint32_t)r1 * row_bytes, 0x00020000);
+    const int n = r1 - r0;
+    const int cnt = n > w ? (n - w + T - 1) / T : 0;
+    uint32_t voff = 4u * c + (uint32_t)(r0 + w) * row_bytes;
+    const uint32_t step = (uint32_t)T * row_bytes;
+    if (PATTERN == 4) {
+      for (int i = 0; i < cnt; i += 2 * D) {
+        uint32_t a[D], b[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) { a[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 2); voff += step; }
+#pragma unroll
+        for (int j = 0; j < D; ++j) { b[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 2); voff += step; }
+#pragma unroll
+        for (int j = 0; j < D; ++j) acc ^= a[j];
+#pragma unroll
+        for (int j = 0; j < D; ++j) acc ^= b[j];
+      }
+    } else {
+      uint32_t ring[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) { ring[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 2); voff += step; }
+      for (int i = 0; i < cnt; i += D) {
+#pragma unroll
+        for (int j = 0; j < D; j += 2) {
+          acc ^= ring[j] ^ ring[j + 1];
+          __builtin_amdgcn_sched_barrier(0);
+          ring[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 2); voff += step;
+          ring[j + 1] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 2); voff += step;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  if (acc == 0x12345678u) y[0] = 1.f;
+}
+
 struct Shape { int rows, N; const char* name; };
 
 template <int PATTERN, int T, int D, bool NT>
@@ -124,6 +180,39 @@ static void run(const Shape& sh, const std::vector<uint32_t*>& qs, float* y, int
   CHECK(hipGraphExecDestroy(exec)); CHECK(hipGraphDestroy(graph)); CHECK(hipStreamDestroy(s));
 }
 
+template <int PATTERN, int T, int D>
+static void run_buf(const Shape& sh, const std::vector<uint32_t*>& qs, float* y, int wgs) {
+  const size_t total = (size_t)((sh.N + 63) / 64) * sh.rows;
+  const int upw = (int)((total + wgs - 1) / wgs);
+  const int grid = (int)((total + upw - 1) / upw);
+  hipStream_t s;
+  CHECK(hipStreamCreate(&s));
+  auto launch_all = [&]() {
+    for (size_t c = 0; c < qs.size(); ++c)
+      hipLaunchKernelGGL((k_stream_buf<PATTERN, T, D>), dim3(grid), dim3(T * 64), 0, s, qs[c], sh.rows, sh.N, upw, y);
+  };
+  launch_all();
+  CHECK(hipStreamSynchronize(s));
+  hipGraph_t graph; hipGraphExec_t exec;
+  CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+  launch_all();
+  CHECK(hipStreamEndCapture(s, &graph));
+  CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  CHECK(hipGraphLaunch(exec, s));
+  CHECK(hipStreamSynchronize(s));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  double sum = 0; const int reps = 4;
+  for (int r = 0; r < reps; ++r) {
+    CHECK(hipEventRecord(e0, s)); CHECK(hipGraphLaunch(exec, s)); CHECK(hipEventRecord(e1, s)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    sum += ms * 1e3 / qs.size();
+  }
+  const double bytes = (double)sh.rows * sh.N * 4;
+  printf("%-8s %5.1f MB pattern %d T=%2d D=%2d nt wgs=%4d grid=%4d: %7.2f us/launch  %6.0f GB/s\n", sh.name, bytes / 1e6, PATTERN, T, D, wgs, grid, sum / reps, bytes / (sum / reps) / 1e3);
+  CHECK(hipGraphExecDestroy(exec)); CHECK(hipGraphDestroy(graph)); CHECK(hipStreamDestroy(s));
+}
+
 int main() {
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
@@ -144,6 +233,10 @@ int main() {
     run<0, 8, 8, true>(sh, qs, y, 4 * cus);
     run<0, 4, 8, true>(sh, qs, y, 8 * cus);
     run<3, 16, 8, true>(sh, qs, y, cus);
+    run_buf<4, 8, 8>(sh, qs, y, cus);
+    run_buf<5, 8, 8>(sh, qs, y, cus);
+    run_buf<5, 8, 16>(sh, qs, y, cus);
+    run_buf<5, 16, 8>(sh, qs, y, cus);
     run<1, 16, 2, true>(sh, qs, y, cus);
     run<1, 16, 4, true>(sh, qs, y, cus);
     run<1, 8, 4, true>(sh, qs, y, cus);
