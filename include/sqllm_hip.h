@@ -248,6 +248,10 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *   "cu_count"        override the CU count used for planning (GPU-less tests)
  *   "mfma_min_batch"  *_batched ops with at least this many rows run on the fp32 matrix cores
  *                     (default 9: the 8-row batch tiles serve smaller batches in one pass)
+ *   "cols_min_batch", "cols_max_batch"
+ *                     *_batched ops with cols_min_batch .. cols_max_batch rows (default 2 .. 4; below
+ *                     mfma_min_batch) run on the column-lane kernel (lane = output column, vec in
+ *                     SGPRs); the other small batches on the batch tiles of the batch-1 kernel
  *   "validate_csr"    debugging aid, default 0.  1 = before every launch that carries a CSR term,
  *                     check ON THE DEVICE that rows[] is non-decreasing with rows[0] == 0 and
  *                     rows[N] == nnz, and return SQLLM_E_SPARSE otherwise.  Blocks the host (one

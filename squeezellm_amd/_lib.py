@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, c_char_p, c_int, c_int32, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsqllm_hip.so")
+# SQLLM_LIB: measurement aid -- load a variant build of the same library (tools/ab_libs.sh) instead
+LIB_PATH = os.environ.get("SQLLM_LIB") or os.path.join(HERE, "libsqllm_hip.so")
 
 
 class SqllmOp(ctypes.Structure):

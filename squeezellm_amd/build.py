@@ -58,6 +58,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         extra.append("-DSQLLM_PIPE=" + str(int(os.environ["SQLLM_PIPE"])))
     if os.environ.get("SQLLM_SCHED_PATTERN"):  # measurement builds: fixed decode-stage schedules
         extra.append("-DSQLLM_SCHED_PATTERN=" + str(int(os.environ["SQLLM_SCHED_PATTERN"])))
+    extra += os.environ.get("SQLLM_EXTRA_DEFINES", "").split()  # measurement builds: e.g. "-DSQLLM_MFMA_VAR=4"
     cmd = [hipcc(), f"--offload-arch={ARCH}", *FLAGS, *extra, "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH + ".tmp"]
     if verbose:

@@ -24,6 +24,8 @@ struct Knobs {
   std::atomic<int> sparse_last{0};
   std::atomic<int> ablate_csr{0};
   std::atomic<int> mfma_min_batch{9};  // *_batched ops with at least this many rows take the matrix-core kernel
+  std::atomic<int> cols_min_batch{2};   // *_batched ops with cols_min_batch .. cols_max_batch rows take the column-lane kernel
+  std::atomic<int> cols_max_batch{4};   // (measured: ahead of the batch tiles up to 4 rows, behind them at 8)
   std::atomic<int> validate_csr{0};    // debug: check rows[] on the device before every launch that carries a CSR term
   std::atomic<void*> timeline{nullptr};  // measurement build: per-workgroup timestamp buffer
 };
@@ -135,33 +137,68 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1)
 }
 
 // Geometry of the wide-batch (matrix-core) kernel: one pass covers 16 * mb batch rows (blockIdx.y
-// walks the passes); the K slices are cut so that about 2 workgroups per CU exist in total (measured
-// flat between 2 and 5 slices; fewer slices = fewer atomics per output); a slice is a whole number
-// of workgroup steps (waves x 4 units), as in make_plan.
+// walks the passes).  The dense work of a pass is the FLATTENED (column tile, unit) space cut into
+// equal contiguous ranges, one per workgroup, as many as the chip holds at once (2 per CU; 1 for
+// the 64-row kernels, by their registers) divided by the number of passes: one round of
+// workgroups, none of them short (N / 64 is rarely a multiple of the CU count: cutting K slices per
+// column tile left the last round 27 % full on the 13B gate/up shape).  A range is a whole number
+// of workgroup steps (waves x 4 units); one that crosses a tile boundary costs a second piece.
 void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm) {
   make_plan(op, gm, 1);
   const int mb = sqllm::mfma_row_blocks(gm->batch);
   const int grid_y = (gm->batch + 16 * mb - 1) / (16 * mb);
   const int step = sqllm::kWaves * 4;
-  int upw = knobs().groups_per_wave.load(std::memory_order_relaxed) * sqllm::kWaves;
+  const long long total_units = (long long)gm->col_tiles * gm->units_total;
+  long long upw = (long long)knobs().groups_per_wave.load(std::memory_order_relaxed) * step;
   if (upw <= 0) {
     int target = knobs().target_wgs.load(std::memory_order_relaxed);
-    if (target <= 0) target = 2 * cu_count();
-    int slices = (target + gm->col_tiles * grid_y - 1) / (gm->col_tiles * grid_y);
-    if (slices < 1) slices = 1;
-    if (slices > sqllm::kMaxSlices) slices = sqllm::kMaxSlices;
-    upw = (gm->units_total + slices - 1) / slices;
+    if (target <= 0) target = (mb == 4 ? 1 : 2) * cu_count();
+    long long ranges = (target + grid_y - 1) / grid_y;
+    if (ranges < 1) ranges = 1;
+    upw = (total_units + ranges - 1) / ranges;
   }
   upw = (upw + step - 1) / step * step;
-  gm->units_per_wg = upw;
-  gm->k_slices = (gm->units_total + upw - 1) / upw;
-  gm->dense_blocks = gm->col_tiles * gm->k_slices;
+  if (upw > 0x3fffffff) upw = 0x3fffffff / step * step;
+  gm->units_per_wg = (int)upw;
+  gm->k_slices = (int)((gm->units_total + upw - 1) / upw);  // pieces per column tile (reported by plan_query)
+  gm->dense_blocks = (int)((total_units + upw - 1) / upw);
   gm->sparse_last = 0;
   gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
 }
 
 bool takes_mfma_path(const sqllm_op* op) {
   return op->batch >= 1 && op->batch >= knobs().mfma_min_batch.load(std::memory_order_relaxed);
+}
+
+// Geometry of the small-batch column-lane kernel: passes of batch_tile(batch) <= 8 rows
+// (blockIdx.y); the dense work of a pass is cut into equal ranges of the flattened
+// (column tile, unit) space like make_plan_mfma's, three workgroups per CU (the phases of a
+// workgroup -- table build, decode, combine -- hide behind its neighbours').
+void make_plan_cols(const sqllm_op* op, sqllm::KernelGeom* gm) {
+  make_plan(op, gm, 1);
+  const int bt = sqllm::batch_tile(gm->batch);
+  const int grid_y = (gm->batch + bt - 1) / bt;
+  const long long total_units = (long long)gm->col_tiles * gm->units_total;
+  long long upw = (long long)knobs().groups_per_wave.load(std::memory_order_relaxed) * sqllm::kWaves;
+  if (upw <= 0) {
+    int target = knobs().target_wgs.load(std::memory_order_relaxed);
+    if (target <= 0) target = 3 * cu_count();
+    long long ranges = (target + grid_y - 1) / grid_y;
+    if (ranges < 1) ranges = 1;
+    upw = (total_units + ranges - 1) / ranges;
+  }
+  upw = (upw + sqllm::kWaves - 1) / sqllm::kWaves * sqllm::kWaves;
+  if (upw > 0x3fffffff) upw = 0x3fffffff / sqllm::kWaves * sqllm::kWaves;
+  gm->units_per_wg = (int)upw;
+  gm->k_slices = (int)((gm->units_total + upw - 1) / upw);
+  gm->dense_blocks = (int)((total_units + upw - 1) / upw);
+  gm->sparse_last = 0;
+  gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
+}
+
+bool takes_cols_path(const sqllm_op* op) {
+  return !takes_mfma_path(op) && op->batch >= 1 && op->batch >= knobs().cols_min_batch.load(std::memory_order_relaxed) &&
+         op->batch <= knobs().cols_max_batch.load(std::memory_order_relaxed);
 }
 
 }  // namespace
@@ -199,6 +236,8 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "sparse_last")) { knobs().sparse_last.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { knobs().cu_count.store(value); return SQLLM_OK; }  // for GPU-less planning tests
   if (!strcmp(name, "mfma_min_batch")) { knobs().mfma_min_batch.store(value < 1 ? 1 : value); return SQLLM_OK; }
+  if (!strcmp(name, "cols_min_batch")) { knobs().cols_min_batch.store(value < 1 ? 1 : value); return SQLLM_OK; }
+  if (!strcmp(name, "cols_max_batch")) { knobs().cols_max_batch.store(value); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { knobs().validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
 #ifdef SQLLM_ABLATION_BUILD
   if (!strcmp(name, "ablate")) { knobs().ablate.store(value); return SQLLM_OK; }
@@ -213,6 +252,8 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "groups_per_wave")) { *value = knobs().groups_per_wave.load(); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { *value = knobs().cu_count.load(); return SQLLM_OK; }
   if (!strcmp(name, "mfma_min_batch")) { *value = knobs().mfma_min_batch.load(); return SQLLM_OK; }
+  if (!strcmp(name, "cols_min_batch")) { *value = knobs().cols_min_batch.load(); return SQLLM_OK; }
+  if (!strcmp(name, "cols_max_batch")) { *value = knobs().cols_max_batch.load(); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { *value = knobs().validate_csr.load(); return SQLLM_OK; }
   return SQLLM_E_OPTION;
 }
@@ -226,6 +267,7 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   sqllm::KernelGeom gm;
   const bool mfma = takes_mfma_path(op);
   if (mfma) make_plan_mfma(op, &gm);
+  else if (takes_cols_path(op)) make_plan_cols(op, &gm);
   else make_plan(op, &gm);
   plan->col_tiles = gm.col_tiles;
   plan->k_slices = gm.k_slices;
@@ -253,8 +295,10 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
                                     hipEvent_t e1, const sqllm_linear* lin = nullptr) {
   if (n < 1 || n > sqllm::kMaxSegments) return SQLLM_E_GROUP;
   if (!ops && !lin) return SQLLM_E_NULL;
-  if (!lin && takes_mfma_path(&ops[0])) {
-    // wide batches: one matrix-core launch per op (the members of a group only share their input)
+  if (!lin && (takes_mfma_path(&ops[0]) || takes_cols_path(&ops[0]))) {
+    // batched operators: one launch per op (the members of a group only share their input) of the
+    // matrix-core kernel (wide batches) or of the column-lane kernel (small ones)
+    const bool mfma = takes_mfma_path(&ops[0]);
     for (int i = 0; i < n; ++i) {
       const sqllm_op* op = &ops[i];
       int rc = validate(op);
@@ -278,10 +322,12 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       sg.vals = op->vals;
       sg.full_rows = op->topX > 0 ? op->full_rows : nullptr;
       sg.full_idx = op->topX > 0 ? op->full_row_indices : nullptr;
-      make_plan_mfma(op, &sg.gm);
+      if (mfma) make_plan_mfma(op, &sg.gm);
+      else make_plan_cols(op, &sg.gm);
       a.ga.block0[0] = 0;
       for (int j = 1; j <= sqllm::kMaxSegments; ++j) a.ga.block0[j] = sg.gm.dense_block0 + sg.gm.dense_blocks;
-      rc = static_cast<int>(sqllm::launch_batched_mfma(op->bits, a, static_cast<hipStream_t>(stream)));
+      rc = static_cast<int>(mfma ? sqllm::launch_batched_mfma(op->bits, a, static_cast<hipStream_t>(stream))
+                                 : sqllm::launch_batched_cols(op->bits, a, static_cast<hipStream_t>(stream)));
       if (rc != SQLLM_OK) return rc;
     }
     return SQLLM_OK;

@@ -93,6 +93,7 @@ inline int mfma_row_blocks(int batch) { return batch <= 16 ? 1 : batch <= 32 ? 2
 
 hipError_t launch_fused(int bits, const LaunchArgs& a, hipStream_t stream);
 hipError_t launch_batched_mfma(int bits, const LaunchArgs& a, hipStream_t stream);
+hipError_t launch_batched_cols(int bits, const LaunchArgs& a, hipStream_t stream);
 hipError_t check_csr(const int* rows, int N, int nnz, hipStream_t stream, int* bad);
 
 }  // namespace sqllm

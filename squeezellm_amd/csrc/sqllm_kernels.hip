@@ -1414,21 +1414,61 @@ __device__ __forceinline__ void dense_role_mfma(const float* __restrict__ x, con
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, grp = lane >> 4;
-  const int ct = bid % n_col_tiles;
-  const int ks = bid / n_col_tiles;
-  const int col0 = ct * kTileN;
+  if constexpr ((SQLLM_MFMA_VAR & 64) != 0) {
+    // measurement: STATIC, DIFFERENT priorities for the waves that share a SIMD (waves w and w + 4 of a
+    // workgroup; with bit 128 also the co-resident workgroup, which is 256 ids away), so that they
+    // fall out of step: one decodes while the other holds the matrix pipe
+    const int pr = (wave >> 2) + ((SQLLM_MFMA_VAR & 128) ? 2 * ((bid >> 8) & 1) : 0);
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+  }
   // LDS: codebooks at address 0 in the layout of dense_role (conflict-free lookups), then the x tiles
   // (one per wave); the epilogue's slabs live where the tiles were
   constexpr int kCb = mfma_codebook_floats(BITS);
   float* slabs = lds + kCb;
   float* xt = lds + kCb + wave * (TR * kXtStride);
-
-  // ---- codebook loads (staged row-wise exactly as in dense_role) ----
   constexpr int EPW = 32 / WAVES, RPW = 16 / WAVES;
   constexpr int NE = (BITS == 4) ? EPW : RPW;
-  float ev[NE];
   const int st_j = (BITS == 4) ? 2 * (wave & 1) + (lane >> 5) : (wave & 3);
   const int st_h = (BITS == 4) ? (wave >> 1) : (wave >> 2);
+  const int row_stride = N / 4;  // in 16-byte units
+  const char* qbase = reinterpret_cast<const char*>(q);
+  const uint32_t row_bytes = 16u * (uint32_t)row_stride;
+  // vec pieces: lane -> (tile row l / 8 + 8 j, lane row piece >> 1 of the group, half piece & 1)
+  int xrow[XL];
+#pragma unroll
+  for (int j = 0; j < XL; ++j) {
+    int r = m0 + (lane >> 3) + 8 * j;
+    if (r > batch - 1) r = batch - 1;  // rows past the batch re-read its last row; never stored
+    xrow[j] = r * K + 4 * (lane & 1);
+  }
+  const int xkq = (lane >> 1) & 3;  // which lane row's k's this lane's pieces belong to
+  const uint32_t lane_off = 4 * (i16 + 16 * (grp & 1));
+  uint32_t tb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) tb[j] = j * SUBB + 4 * (i16 + 16 * (grp & 1));
+  float* xt_w = xt + (lane >> 3) * kXtStride + 8 * xkq + 4 * (lane & 1);  // where this lane parks its pieces
+  const float* xt_r = xt + i16 * kXtStride + 8 * grp;                     // batch row i16 of block 0, this lane row's 8 k's
+
+  // ---- this workgroup's share: units [bid * units_per_wg, + units_per_wg) of the FLATTENED
+  // (column tile, unit) space -- every workgroup the same number of units whatever N and K are, all
+  // of them resident at once (one round, no tail).  A range that crosses a tile boundary is worked
+  // off as two pieces (codebooks restaged, sums flushed in between). ----
+  const unsigned total = (unsigned)n_col_tiles * (unsigned)units_total;
+  unsigned gpos = (unsigned)bid * (unsigned)units_per_wg;
+  unsigned gend = gpos + (unsigned)units_per_wg;
+  if (gend > total) gend = total;
+  while (gpos < gend) {
+  const int ct = (int)(gpos / (unsigned)units_total);
+  const int u_beg = (int)(gpos - (unsigned)ct * (unsigned)units_total);
+  int u_end = units_total;
+  if ((unsigned)(u_end - u_beg) > gend - gpos) u_end = u_beg + (int)(gend - gpos);
+  gpos += (unsigned)(u_end - u_beg);
+  const int col0 = ct * kTileN;
+
+  // ---- codebook loads (staged row-wise exactly as in dense_role) ----
+  float ev[NE];
   {
     int c = col0 + 4 * i16 + st_j;
     if (c > N - 1) c = N - 1;
@@ -1444,27 +1484,12 @@ __device__ __forceinline__ void dense_role_mfma(const float* __restrict__ x, con
       for (int i = 0; i < RPW; ++i) ev[i] = src[2 * (st_h * RPW + i) + (lane >> 5)];
     }
   }
-  // ---- this workgroup's K range; a wave's group g = units u_beg + 4 (wave + WAVES g) + grp ----
-  const int u_beg = ks * units_per_wg;
-  int u_end = u_beg + units_per_wg;
-  if (u_end > units_total) u_end = units_total;
+  // ---- a wave's group g of this piece = units u_beg + 4 (wave + WAVES g) + grp ----
   const int n_groups_wg = (u_end - u_beg + 3) / 4;
   const int n_g = n_groups_wg > wave ? (n_groups_wg - wave + WAVES - 1) / WAVES : 0;
-  const int row_stride = N / 4;  // in 16-byte units
   int cidx = col0 / 4 + i16;
   if (cidx > row_stride - 1) cidx = row_stride - 1;
-  const char* qbase = reinterpret_cast<const char*>(q);
   const uint32_t lane_bytes = 16u * (uint32_t)cidx;
-  const uint32_t row_bytes = 16u * (uint32_t)row_stride;
-  // vec pieces: lane -> (tile row l / 8 + 8 j, lane row piece >> 1 of the group, half piece & 1)
-  int xrow[XL];
-#pragma unroll
-  for (int j = 0; j < XL; ++j) {
-    int r = m0 + (lane >> 3) + 8 * j;
-    if (r > batch - 1) r = batch - 1;  // rows past the batch re-read its last row; never stored
-    xrow[j] = r * K + 4 * (lane & 1);
-  }
-  const int xkq = (lane >> 1) & 3;  // which lane row's k's this lane's pieces belong to
   auto group_unit = [&](int g, int kq) {  // unit of lane row kq in this wave's group g (may be >= u_end)
     return u_beg + 4 * (wave + WAVES * g) + kq;
   };
@@ -1472,6 +1497,7 @@ __device__ __forceinline__ void dense_role_mfma(const float* __restrict__ x, con
     int u = group_unit(g, grp);
     if (u > u_end - 1) u = u_end - 1;  // clamped re-read inside the slice; its x pieces are zeroed
     if (u < u_beg) u = u_beg;
+    if (SQLLM_MFMA_VAR & 32) u = u_beg + grp;  // measurement: every group re-reads the slice's first rows (cache hits)
     const uint32_t off = (uint32_t)(u * R) * row_bytes + lane_bytes;
 #pragma unroll
     for (int r = 0; r < R; ++r) dw[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(qbase + (off + r * row_bytes)));
@@ -1482,6 +1508,7 @@ __device__ __forceinline__ void dense_role_mfma(const float* __restrict__ x, con
     int u = group_unit(g, xkq);
     if (u > u_end - 1) u = u_end - 1;
     if (u < u_beg) u = u_beg;
+    if ((SQLLM_MFMA_VAR & 16) && g > 0) return;  // measurement: no vec loads after the first group
 #pragma unroll
     for (int j = 0; j < XL; ++j) dx[j] = *reinterpret_cast<const f32x4*>(x + xrow[j] + u * KU + 8 * ph);
   };
@@ -1506,13 +1533,7 @@ __device__ __forceinline__ void dense_role_mfma(const float* __restrict__ x, con
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const uint32_t lane_off = 4 * (i16 + 16 * (grp & 1));
-  uint32_t tb[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) tb[j] = j * SUBB + 4 * (i16 + 16 * (grp & 1));
-  float* xt_w = xt + (lane >> 3) * kXtStride + 8 * xkq + 4 * (lane & 1);  // where this lane parks its pieces
-  const float* xt_r = xt + i16 * kXtStride + 8 * grp;                     // batch row i16 of block 0, this lane row's 8 k's
-  __syncthreads();  // codebooks staged, sums zeroed
+  __syncthreads();  // codebooks staged (and everybody has left the previous piece's slabs)
 
   // one phase: 8 k's of each lane row against all MB row blocks; v[j][s] = weight s of column 4c + j
   auto phase = [&](const float (&v)[4][8], const f32x4 (&dx)[XL], int g) {
@@ -1654,6 +1675,7 @@ __device__ __forceinline__ void dense_role_mfma(const float* __restrict__ x, con
       if (r < batch && col < N) acc_add(y + (size_t)r * N + col, sum);
     }
   }
+  }  // pieces
 }
 
 template <int BITS, int MB, int WAVES>
@@ -1683,6 +1705,282 @@ sqllm_fused_batched(const float* x, const GroupArgs ga) {
     }
   } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
     topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, m0, rows_here, sp - gm.csr_blocks, lds);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small-batch dense role (the *_batched operators from 2 rows up to the matrix-core switch-over):
+// lane = OUTPUT COLUMN, every k wave-uniform.
+//
+// The batch tiles of dense_role broadcast vec across 16-lane rows (one DPP move + half a packed FMA
+// per weight and batch row) and the matrix-core kernel cannot hide its decode behind the fp32
+// matrix instructions (on gfx950 v_mfma_f32_16x16x4_f32 and vector / LDS work ADD:
+// tools/experiments/issue_rate.hip, "phases" rows), so between 2 and ~16 rows both cost 2-3 x the
+// batch-1 launch.  Here a lane owns one column:
+//     * a wave load is 64 columns x one qweight row (256 contiguous bytes); wave w of the workgroup
+//       takes units u0 + w, u0 + w + WAVES, ... of the piece, D units per load batch, two batches in
+//       flight (raw buffer loads whose descriptor ends with the piece: a unit past it returns 0
+//       without touching memory, so the loop has one static shape);
+//     * vec is WAVE-UNIFORM: it comes from SGPRs (s_load through the constant address space) and
+//       is the scalar operand of v_pk_fma_f32 -- no DPP, no LDS traffic, no VALU instruction for
+//       vec at all; per weight and batch row the loop issues HALF a vector instruction;
+//     * 4-bit: 16-entry codebooks transposed in LDS ([entry][column], 4 KB: any 64 lookups are
+//       conflict-free), address = one v_perm_b32 per weight; 3-bit: 64-entry PAIR tables
+//       ([i0 + 8 i1][column] x {lut[i0], lut[i1]}, 32 KB): one ds_read_b64 per two weights;
+//     * decode is a software pipeline over stages of ST k's (ST * rows <= 32 SGPRs of vec):
+//       [wait] [issue lookups + vec loads of stage s + 1] [packed FMAs of stage s]; scalar loads
+//       return out of order, so the wait is lgkmcnt(0) and sits in front of the next issue.
+// Work is cut as in the matrix-core kernel: equal contiguous ranges of the flattened
+// (column tile, unit) space, one per workgroup, a range crossing a tile boundary = two pieces.
+// Waves meet in LDS slabs (plain stores) and leave as one atomic per (row, column).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+// one extra, all-zero entry row behind each table: a unit past the end of a wave's share looks it up
+constexpr int cols_table_floats(int bits) { return bits == 4 ? 17 * 64 : 65 * 64 * 2; }
+constexpr int cols_lds_floats(int bits, int bt, int waves) {
+  return cmax(cols_table_floats(bits) + waves * bt * 64, cmax(2 * kCsrSpanMax, kTopxLds));
+}
+constexpr int cols_stage_k(int bt) { return bt * 8 <= 32 ? 8 : 4; }  // k's per pipeline stage
+
+// 6-bit field M (weights 2M, 2M + 1 of a 3-bit unit) times 512, ready to be OR-ed into a pair-table address
+__device__ __forceinline__ uint32_t field6_x512(uint32_t t0, uint32_t t1, uint32_t t2, int M) {
+  const int bit = 6 * M, w = bit >> 5, o = bit & 31;
+  const uint32_t lo = (w == 0) ? t0 : (w == 1) ? t1 : t2;
+  uint32_t f;
+  if (o <= 26) {
+    if (o > 9) f = lo >> (o - 9);
+    else if (o < 9) f = lo << (9 - o);
+    else f = lo;
+  } else {
+    const uint32_t hi = (w == 0) ? t1 : t2;
+    f = __builtin_amdgcn_alignbit(hi, lo, o) << 9;
+  }
+  return f & 0x7E00u;
+}
+
+// vec -> SGPRs: scalar loads through the constant address space, base (one SGPR pair) + byte offset.
+typedef const __attribute__((address_space(4))) float* cfloatp;
+typedef const __attribute__((address_space(4))) char* ccharp;
+template <int ST> struct XVec;
+template <> struct XVec<4> {
+  typedef f32x4 type;
+  static __device__ __forceinline__ type load(ccharp base, uint32_t off) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) type*>(base + off);  // (16-byte aligned: K % 32 == 0)
+  }
+};
+template <> struct XVec<8> {
+  typedef f32x8 type;
+  static __device__ __forceinline__ type load(ccharp base, uint32_t off) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) type*>(base + off);
+  }
+};
+
+template <int BITS, int BT, int WAVES>
+__device__ __forceinline__ void dense_role_cols(const float* __restrict__ x, const uint32_t* __restrict__ q,
+                                                float* __restrict__ y, const float* __restrict__ lut, int K, int N,
+                                                int b0, int nb, int bid, int n_col_tiles, int units_total,
+                                                int units_per_wg, float* lds) {
+  using F = Fmt<BITS>;
+  constexpr int L = F::kLut, R = F::kRows, KU = F::kK;
+  constexpr int ST = cols_stage_k(BT);        // k's per stage
+  constexpr int SPU = KU / ST;                // stages per unit
+  constexpr int D = BITS == 4 ? 4 : 2;        // units per load batch ("chunk")
+  constexpr int NB = 2;                       // chunks in flight
+  constexpr int NS = D * SPU;                 // stages per chunk
+  constexpr int NP = ST / 2;                  // weight pairs per stage
+  constexpr int NA = BT >= 4 ? 1 : 4 / BT;    // accumulators per batch row (FMA chains in flight)
+  using XV = typename XVec<ST>::type;
+  static_assert(NS % 2 == 0, "stages alternate between two register sets");
+  static_assert(WAVES == 8, "table build assumes 8 waves");
+  __builtin_amdgcn_s_waitcnt(0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* table = reinterpret_cast<char*>(lds);
+  float* slabs = lds + cols_table_floats(BITS);
+  // 4-bit: byte 1 of the lane word is the index of the zero row -- a lookup's v_perm takes its entry
+  // index from the data (selector 4..7) or, for a unit that does not exist, from here (selector 1)
+  const uint32_t lane_base = BITS == 4 ? (4u * lane) | 0x1000u : 8u * lane;
+  const uint32_t row_bytes = 4u * (uint32_t)N;
+  // rows of this pass (rows past the batch re-read its last row; never stored): one base pointer each,
+  // so that a vec load is  base + the stage's byte offset  with no scalar arithmetic of its own
+  ccharp xrow[BT];
+#pragma unroll
+  for (int b = 0; b < BT; ++b) xrow[b] = reinterpret_cast<ccharp>(reinterpret_cast<uintptr_t>(x + (size_t)(b0 + (b < nb ? b : nb - 1)) * K));
+  uint32_t soff[D][R];
+#pragma unroll
+  for (int j = 0; j < D; ++j)
+#pragma unroll
+    for (int r = 0; r < R; ++r) soff[j][r] = (uint32_t)(j * WAVES * R + r) * row_bytes;
+  // the zero rows of the tables (never rewritten)
+  if constexpr (BITS == 4) { if (tid < 64) *reinterpret_cast<float*>(table + 16 * 256 + 4 * tid) = 0.f; }
+  else { if (tid < 64) *reinterpret_cast<f32x2*>(table + 64 * 512 + 8 * tid) = f32x2{0.f, 0.f}; }
+
+  const unsigned total = (unsigned)n_col_tiles * (unsigned)units_total;
+  unsigned gpos = (unsigned)bid * (unsigned)units_per_wg;
+  unsigned gend = gpos + (unsigned)units_per_wg;
+  if (gend > total) gend = total;
+  bool first = true;
+  while (gpos < gend) {
+    const int ct = __builtin_amdgcn_readfirstlane((int)(gpos / (unsigned)units_total));  // (the division runs on the VALU)
+    const int u0 = (int)(gpos - (unsigned)ct * (unsigned)units_total);
+    int u1 = units_total;
+    if ((unsigned)(u1 - u0) > gend - gpos) u1 = u0 + (int)(gend - gpos);
+    gpos += (unsigned)(u1 - u0);
+    const int col0 = ct * kTileN;
+    const int col = col0 + lane;
+    const int colc = col < N ? col : N - 1;
+    // ---- codebook values for the table rows this wave builds, then the first NB chunks ----
+    const float* lp = lut + (size_t)colc * L;
+    float tv[8];
+    float thi = 0.f;
+    if constexpr (BITS == 4) {
+      const f32x2 t = *reinterpret_cast<const f32x2*>(lp + 2 * w);
+      tv[0] = t.x; tv[1] = t.y;
+    } else {
+      const f32x4 ta = *reinterpret_cast<const f32x4*>(lp), tb2 = *reinterpret_cast<const f32x4*>(lp + 4);
+      tv[0] = ta.x; tv[1] = ta.y; tv[2] = ta.z; tv[3] = ta.w; tv[4] = tb2.x; tv[5] = tb2.y; tv[6] = tb2.z; tv[7] = tb2.w;
+      thi = lp[w];
+    }
+    const int n_units = u1 - u0;
+    const int n_w = n_units > w ? (n_units - w + WAVES - 1) / WAVES : 0;  // units of this wave: u0 + w + WAVES i
+    const int nc = (n_w + D - 1) / D;
+    const __amdgpu_buffer_rsrc_t qrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(q), 0, (uint32_t)(u1 * R) * row_bytes, 0x00020000);
+    uint32_t voff[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) voff[k] = 4u * (uint32_t)colc + (uint32_t)((u0 + w + k * D * WAVES) * R) * row_bytes;
+    auto load_chunk = [&](int k, uint32_t (&dst)[D][R]) {
+#pragma unroll
+      for (int j = 0; j < D; ++j)
+#pragma unroll
+        for (int r = 0; r < R; ++r) dst[j][r] = __builtin_amdgcn_raw_buffer_load_b32(qrsrc, voff[k], soff[j][r], 2 /* nt */);
+      voff[k] += (uint32_t)(NB * D * WAVES * R) * row_bytes;
+    };
+    uint32_t wbuf[NB][D][R];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) load_chunk(k, wbuf[k]);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (!first) __syncthreads();  // everybody has left the previous piece's table and slabs
+    first = false;
+    if constexpr (BITS == 4) {
+      *reinterpret_cast<float*>(table + (2 * w) * 256 + 4 * lane) = tv[0];
+      *reinterpret_cast<float*>(table + (2 * w + 1) * 256 + 4 * lane) = tv[1];
+    } else {
+#pragma unroll
+      for (int i0 = 0; i0 < 8; ++i0) *reinterpret_cast<f32x2*>(table + (8 * w + i0) * 512 + lane_base) = f32x2{tv[i0], thi};
+    }
+    __syncthreads();
+
+    f32x2 acc[BT][NA];
+#pragma unroll
+    for (int b = 0; b < BT; ++b)
+#pragma unroll
+      for (int a = 0; a < NA; ++a) acc[b][a] = f32x2{0.f, 0.f};
+    struct St { f32x2 v[NP]; XV x[BT]; };
+    // issue stage st of chunk cc (held in buf): lookups + vec loads.  A unit past the wave's last one
+    // (its weight words are zeros, but entry 0 of a codebook need not be) looks up the zero row -- the
+    // choice is a scalar select of the v_perm selector (4-bit) or one OR per unit (3-bit) -- and
+    // re-reads the vec of the piece's last unit.
+    auto issue = [&](const uint32_t (&buf)[D][R], int st, int cc, St& o) {
+      const int j = st / SPU, sub = st % SPU;
+      const int i = cc * D + j;
+      const bool live = i < n_w;
+      if constexpr (BITS == 4) {
+        const uint32_t lo = buf[j][0] & 0x0F0F0F0Fu, hi = (buf[j][0] >> 4) & 0x0F0F0F0Fu;
+#define SQ_L(WORD, SEL) *reinterpret_cast<const float __attribute__((address_space(3)))*>(__builtin_amdgcn_perm(WORD, lane_base, SEL))
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+          const uint32_t sel = live ? 0x0C0C0400u + ((uint32_t)(sub * NP + m) << 8) : 0x0C0C0100u;
+          o.v[m] = f32x2{SQ_L(lo, sel), SQ_L(hi, sel)};
+        }
+#undef SQ_L
+      } else {
+        const uint32_t lane_or_dead = lane_base | (live ? 0u : 0x8000u);
+#pragma unroll
+        for (int m = 0; m < NP; ++m)
+          o.v[m] = *reinterpret_cast<const f32x2 __attribute__((address_space(3)))*>(
+              lane_or_dead | field6_x512(buf[j][0], buf[j][1], buf[j][2], sub * NP + m));
+      }
+      int u = u0 + w + i * WAVES;
+      if (u > u1 - 1) u = u1 - 1;
+      uint32_t koff = 4u * (uint32_t)(u * KU + sub * ST);
+      asm volatile("" : "+s"(koff));  // (keeps the compiler from turning the 8 offsets into 8 induction variables)
+#pragma unroll
+      for (int b = 0; b < BT; ++b) o.x[b] = XVec<ST>::load(xrow[b], koff);
+    };
+    auto fmas = [&](const St& o) {
+#pragma unroll
+      for (int m = 0; m < NP; ++m)
+#pragma unroll
+        for (int b = 0; b < BT; ++b)
+          acc[b][m % NA] = __builtin_elementwise_fma(o.v[m], f32x2{o.x[b][2 * m], o.x[b][2 * m + 1]}, acc[b][m % NA]);
+    };
+    St sa, sb;
+    issue(wbuf[0], 0, 0, sa);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < nc; c += NB) {
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+#pragma unroll
+        for (int st = 0; st < NS; st += 2) {
+          // the wait for stage s goes BEFORE the issue of stage s + 1 (behind it, it would wait for the new lookups too)
+          __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+          issue(wbuf[k], st + 1, c + k, sb);
+          __builtin_amdgcn_sched_barrier(0);
+          fmas(sa);
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          if (st + 2 < NS) issue(wbuf[k], st + 2, c + k, sa);
+          else issue(wbuf[(k + 1) % NB], 0, c + k + 1, sa);
+          __builtin_amdgcn_sched_barrier(0);
+          fmas(sb);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        load_chunk(k, wbuf[k]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // ---- waves meet in LDS: slab [wave][row][column], then one atomic per (row, column) ----
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      f32x2 t = acc[b][0];
+#pragma unroll
+      for (int a = 1; a < NA; ++a) t += acc[b][a];
+      slabs[(w * BT + b) * 64 + lane] = t.x + t.y;
+    }
+    __syncthreads();
+    for (int e = tid; e < BT * 64; e += WAVES * 64) {
+      const int b = e >> 6, c = e & 63;
+      float sum = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < WAVES; ++ww) sum += slabs[(ww * BT + b) * 64 + c];
+      if (b < nb && col0 + c < N) acc_add(y + (size_t)(b0 + b) * N + col0 + c, sum);
+    }
+  }
+}
+
+template <int BITS, int BT, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+sqllm_fused_cols(const float* x, const GroupArgs ga) {
+  constexpr int T = WAVES * 64;
+  __shared__ __attribute__((aligned(16))) float lds[cols_lds_floats(BITS, BT, WAVES)];
+  const Segment& sg = ga.seg[0];
+  const KernelGeom& gm = sg.gm;
+  const int bid = blockIdx.x;
+  const int b0 = blockIdx.y * BT;
+  int nb = gm.batch - b0;
+  if (nb > BT) nb = BT;
+  const int d = bid - gm.dense_block0;
+  const int sp = bid < gm.dense_block0 ? bid : -1;
+  if (d >= 0 && d < gm.dense_blocks) {
+    dense_role_cols<BITS, BT, WAVES>(x, sg.q, sg.y, sg.lut, gm.K, gm.N, b0, nb, d, gm.col_tiles, gm.units_total,
+                                     gm.units_per_wg, lds);
+  } else if (sp >= 0 && sp < gm.csr_blocks) {
+    csr_role<T, BT, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds, nullptr, 0);
+  } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
+    topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, b0, nb, sp - gm.csr_blocks, lds);
   }
 }
 
@@ -1812,6 +2110,32 @@ static hipError_t launch_mfma_bits(const LaunchArgs& a, hipStream_t stream) {
     case 2: return launch_mfma_inst<BITS, 2>(a, stream);
     default: return launch_mfma_inst<BITS, 4>(a, stream);
   }
+}
+
+template <int BITS, int BT>
+static hipError_t launch_cols_inst(const LaunchArgs& a, hipStream_t stream) {
+  const KernelGeom& gm = a.ga.seg[0].gm;
+  dim3 grid(gm.dense_block0 + gm.dense_blocks, (gm.batch + BT - 1) / BT);
+  auto kern = sqllm_fused_cols<BITS, BT, kWaves>;
+  const float* x = static_cast<const float*>(a.x);
+  if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga);
+  else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga);
+  return hipGetLastError();
+}
+
+template <int BITS>
+static hipError_t launch_cols_bits(const LaunchArgs& a, hipStream_t stream) {
+  switch (batch_tile(a.ga.seg[0].gm.batch)) {
+    case 1: return launch_cols_inst<BITS, 1>(a, stream);
+    case 2: return launch_cols_inst<BITS, 2>(a, stream);
+    case 4: return launch_cols_inst<BITS, 4>(a, stream);
+    default: return launch_cols_inst<BITS, 8>(a, stream);
+  }
+}
+
+// one op (a.ga.seg[0]), operator ABI, small batches: lane = column, vec from SGPRs
+hipError_t launch_batched_cols(int bits, const LaunchArgs& a, hipStream_t stream) {
+  return bits == 4 ? launch_cols_bits<4>(a, stream) : launch_cols_bits<3>(a, stream);
 }
 
 // one op (a.ga.seg[0]), operator ABI, batch rows through the matrix cores

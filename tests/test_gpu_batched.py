@@ -55,6 +55,62 @@ def test_ppl_eval_batch_2048(qc, gpu, bits):
     assert H.rel_err(got, H.oracle_ref(case, x, mul, "hybrid")) <= TOL_FP64
 
 
+def _routing(mfma_min, cols_min, cols_max):
+    from squeezellm_amd import _lib
+
+    _lib.set_option("mfma_min_batch", mfma_min)
+    _lib.set_option("cols_min_batch", cols_min)
+    _lib.set_option("cols_max_batch", cols_max)
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("kind", ["dense", "hybrid"])
+@pytest.mark.parametrize("shape", [(256, 192), (1024, 776), (2048, 1024), (32, 4), (96, 68)])
+def test_column_lane_kernel_vs_oracle(qc, gpu, bits, kind, shape):
+    """The column-lane kernel (default for 2..4 rows) forced for every batch size, ragged shapes included
+    (N not a multiple of the 64-column tile, K of one 3-bit unit, ranges that cross tile boundaries)."""
+    import torch
+
+    K, N = shape
+    case = H.make_case(bits, K, N, sparse=0.02 if kind == "hybrid" else 0, topX=3 if kind == "hybrid" else 0,
+                       heavy_rows=1 if kind == "hybrid" else 0, seed=K + N + bits)
+    t = H.to_torch(case, gpu)
+    try:
+        _routing(1 << 30, 1, 1 << 30)
+        for B in (1, 2, 3, 4, 5, 7, 8, 9, 16, 23):
+            rng = np.random.default_rng(B)
+            x = rng.normal(size=(B, K)).astype(np.float32)
+            mul = rng.normal(size=(B, N)).astype(np.float32)
+            y = torch.from_numpy(mul.copy()).to(gpu)
+            H.call_op(qc, t, torch.from_numpy(x).to(gpu), y, kind, True)
+            torch.cuda.synchronize()
+            assert H.rel_err(y.cpu().numpy(), H.oracle_ref(case, x, mul, kind)) <= TOL_FP64, (B, K, N)
+    finally:
+        _routing(9, 2, 4)
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+def test_three_batched_paths_agree(qc, gpu, bits):
+    """Batch tiles, column-lane kernel and matrix-core kernel are three implementations of one operator."""
+    import torch
+
+    case = H.make_case(bits, 2048, 1024, sparse=0.0045, topX=10, heavy_rows=4, seed=5)
+    t = H.to_torch(case, gpu)
+    for B in (3, 24):
+        x = torch.randn((B, 2048), device=gpu)
+        outs = []
+        try:
+            for routing in ((1 << 30, 1 << 30, 0), (1 << 30, 1, 1 << 30), (1, 1 << 30, 0)):
+                _routing(*routing)
+                y = torch.zeros((B, 1024), device=gpu)
+                H.call_op(qc, t, x, y, "hybrid", True)
+                torch.cuda.synchronize()
+                outs.append(y.cpu().numpy())
+        finally:
+            _routing(9, 2, 4)
+        assert H.rel_err(outs[1], outs[0]) <= 1e-5 and H.rel_err(outs[2], outs[0]) <= 1e-5
+
+
 @pytest.mark.parametrize("bits", [3, 4])
 def test_both_batched_paths_agree(qc, gpu, bits):
     """The 8-row batch tiles and the matrix-core kernel are two implementations of one operator."""

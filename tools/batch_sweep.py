@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Batched operators: parity against the numpy oracle on a small shape and device time per launch by
-batch size, through the 8-row batch tiles (mfma_min_batch = huge) and through the matrix-core
-kernel (mfma_min_batch = 1), on distinct weight copies (HBM-resident stream).
+batch size, through the 8-row batch tiles ("tile"), the column-lane kernel ("cols") and the
+matrix-core kernel ("mfma"), on distinct weight copies (HBM-resident stream).
 
     python tools/batch_sweep.py [--shape 5120x13824] [--bits 4] [--batches 1,2,4,8,16] [--check]
 """
@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--sparse", type=float, default=0.0045)
     ap.add_argument("--topx", type=int, default=10)
     ap.add_argument("--batches", default="1,2,4,8,16,32,64,128")
-    ap.add_argument("--paths", default="tile,mfma")
+    ap.add_argument("--paths", default="tile,cols,mfma")
     ap.add_argument("--total-mb", type=float, default=600.0)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--check", action="store_true", help="parity of the matrix-core path vs the oracle on a small shape")
@@ -36,26 +36,29 @@ def main():
     if args.check:
         import helpers as H
 
-        _lib.set_option("mfma_min_batch", 1)
         worst = 0.0
-        for bits in (3, 4):
-            for kind in ("dense", "spmv", "hybrid"):
-                for (K, N) in ((256, 192), (1024, 776)):
-                    case = H.make_case(bits, K, N, sparse=0.02 if kind != "dense" else 0, topX=5 if kind == "hybrid" else 0,
-                                       heavy_rows=2 if kind != "dense" else 0, seed=K + bits)
-                    t = H.to_torch(case, dev)
-                    for B in (1, 2, 3, 4, 5, 8, 9, 16, 17, 33, 64, 65, 130):
-                        rng = np.random.default_rng(B)
-                        x = rng.normal(size=(B, K)).astype(np.float32)
-                        mul = rng.normal(size=(B, N)).astype(np.float32)
-                        y = torch.from_numpy(mul.copy()).to(dev)
-                        H.call_op(qc, t, torch.from_numpy(x).to(dev), y, kind, True)
-                        torch.cuda.synchronize()
-                        err = H.rel_err(y.cpu().numpy(), H.oracle_ref(case, x, mul, kind))
-                        worst = max(worst, err)
-                        if err > 2e-5:
-                            print("MISMATCH", bits, kind, K, N, B, err, flush=True)
-        print(json.dumps(dict(check="mfma path vs oracle", worst_rel_err=worst, ok=bool(worst <= 2e-5))), flush=True)
+        for path in ("mfma", "cols"):
+          _lib.set_option("mfma_min_batch", 1 if path == "mfma" else 1 << 30)
+          _lib.set_option("cols_min_batch", 1)
+          _lib.set_option("cols_max_batch", 1 << 30)
+          for bits in (3, 4):
+              for kind in ("dense", "spmv", "hybrid"):
+                  for (K, N) in ((256, 192), (1024, 776)):
+                      case = H.make_case(bits, K, N, sparse=0.02 if kind != "dense" else 0, topX=5 if kind == "hybrid" else 0,
+                                         heavy_rows=2 if kind != "dense" else 0, seed=K + bits)
+                      t = H.to_torch(case, dev)
+                      for B in (1, 2, 3, 4, 5, 8, 9, 16, 17, 33, 64, 65, 130):
+                          rng = np.random.default_rng(B)
+                          x = rng.normal(size=(B, K)).astype(np.float32)
+                          mul = rng.normal(size=(B, N)).astype(np.float32)
+                          y = torch.from_numpy(mul.copy()).to(dev)
+                          H.call_op(qc, t, torch.from_numpy(x).to(dev), y, kind, True)
+                          torch.cuda.synchronize()
+                          err = H.rel_err(y.cpu().numpy(), H.oracle_ref(case, x, mul, kind))
+                          worst = max(worst, err)
+                          if err > 2e-5:
+                              print("MISMATCH", path, bits, kind, K, N, B, err, flush=True)
+        print(json.dumps(dict(check="mfma and cols paths vs oracle", worst_rel_err=worst, ok=bool(worst <= 2e-5))), flush=True)
 
     K, N = map(int, args.shape.split("x"))
     one = synth.algorithmic_bytes(K, N, args.bits)
@@ -68,6 +71,8 @@ def main():
         nbytes = synth.layer_bytes(layers[0], B)
         for path in args.paths.split(","):
             _lib.set_option("mfma_min_batch", 1 if path == "mfma" else 1 << 30)
+            _lib.set_option("cols_min_batch", 1 if path == "cols" else 1 << 30)
+            _lib.set_option("cols_max_batch", 1 << 30)
             seq = decode.OpSequence(layers, xs, ys, batched=True)
             seq.profile(reps=1)
             us = seq.profile(reps=args.reps)

@@ -24,7 +24,7 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 enum Kind { K_PERM = 0, K_FMA, K_FMAC_SGPR, K_PKFMA, K_PKFMA_SGPR, K_ANDOR, K_FMAC_DPP, K_LDS32, K_LDS64, K_LDS128,
-            K_MIX4, K_MIX4_FMA, K_MIX3, K_LDSW64, K_LDSW2x32, K_OVL_B64, K_OVL_B32, K_MFMA16, K_MFMA4, K_MFMA32, K_MFMA16V, K_LDSADDF, K_LDSADDU, K_N };
+            K_MIX4, K_MIX4_FMA, K_MIX3, K_LDSW64, K_LDSW2x32, K_OVL_B64, K_OVL_B32, K_MFMA16, K_MFMA4, K_MFMA32, K_MFMA16V, K_MFMA_PHASE, K_MFMA_PHASE_PRIO, K_MFMA_INTER, K_LDSADDF, K_LDSADDU, K_N };
 static const char* kNames[K_N] = {
     "v_perm_b32", "v_fma_f32 (vgpr)", "v_fmac_f32 (sgpr x)", "v_pk_fma_f32 (vgpr)", "v_pk_fma_f32 (sgpr pair x)",
     "v_and_or_b32", "v_fmac_f32 dpp row_newbcast", "ds_read_b32", "ds_read_b64", "ds_read_b128",
@@ -33,10 +33,13 @@ static const char* kNames[K_N] = {
     "overlap: 64 v_perm + 32 ds_read_b64 (independent, one wait per block)", "overlap: 64 v_perm + 32 ds_read_b32 (independent, one wait per block)",
     "v_mfma_f32_16x16x4_f32 (4 independent accumulators)", "v_mfma_f32_4x4x1_16b_f32 (4 independent accumulators)", "v_mfma_f32_32x32x2_f32 (2 independent accumulators)",
     "v_mfma_f32_16x16x4_f32, 8 different A / B registers, RANDOM operand values",
+    "phases: 32 mfma_16x16x4, THEN 64 v_perm + 32 ds_read_b32 + wait",
+    "phases as above, waves of a SIMD at static priorities 0..3",
+    "interleaved: 32 x {mfma_16x16x4, 2 v_perm, 1 ds_read_b32}, wait",
     "ds_add_f32 (64 lanes, 64 different addresses)", "ds_add_u32 (64 lanes, 64 different addresses)"};
 // instructions per block (per loop iteration), and which of them are VALU / LDS
-static const int kValuPerBlock[K_N] = {64, 64, 64, 64, 64, 64, 64, 0, 0, 0, 32, 48, 48, 0, 0, 64, 64, 32, 32, 16, 32, 0, 0};
-static const int kLdsPerBlock[K_N] = {0, 0, 0, 0, 0, 0, 0, 64, 64, 64, 16, 16, 16, 64, 64, 32, 32, 0, 0, 0, 0, 16, 16};
+static const int kValuPerBlock[K_N] = {64, 64, 64, 64, 64, 64, 64, 0, 0, 0, 32, 48, 48, 0, 0, 64, 64, 32, 32, 16, 32, 32, 32, 32, 0, 0};
+static const int kLdsPerBlock[K_N] = {0, 0, 0, 0, 0, 0, 0, 64, 64, 64, 16, 16, 16, 64, 64, 32, 32, 0, 0, 0, 0, 32, 32, 32, 16, 16};
 
 #define REP2(x) x x
 #define REP4(x) REP2(x) REP2(x)
@@ -78,6 +81,12 @@ __global__ void __launch_bounds__(1024) k_rate(unsigned long long* out, int iter
     a4 = __builtin_bit_cast(unsigned, rnd(12)); a5 = __builtin_bit_cast(unsigned, rnd(13)); a6 = __builtin_bit_cast(unsigned, rnd(14)); a7 = __builtin_bit_cast(unsigned, rnd(15));
     mc0 = f32x4{rnd(16), rnd(17), rnd(18), rnd(19)}; mc1 = f32x4{rnd(20), rnd(21), rnd(22), rnd(23)};
     mc2 = f32x4{rnd(24), rnd(25), rnd(26), rnd(27)}; mc3 = f32x4{rnd(28), rnd(29), rnd(30), rnd(31)};
+  }
+  if constexpr (KIND == K_MFMA_PHASE_PRIO) {
+    const int pr = __builtin_amdgcn_readfirstlane(tid >> 8);  // waves w, w + 4, w + 8, w + 12 share a SIMD
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr == 3) __builtin_amdgcn_s_setprio(3);
   }
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -174,6 +183,27 @@ __global__ void __launch_bounds__(1024) k_rate(unsigned long long* out, int iter
                    : "+v"(mc0), "+v"(mc1), "+v"(mc2), "+v"(mc3)
                    : "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4), "v"(f5), "v"(f6), "v"(f7),
                      "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+    } else if constexpr (KIND == K_MFMA_PHASE || KIND == K_MFMA_PHASE_PRIO) {
+      float g0, g1, g2, g3;
+      asm volatile(REP8("v_mfma_f32_16x16x4_f32 %0, %16, %17, %0\n v_mfma_f32_16x16x4_f32 %1, %16, %18, %1\n v_mfma_f32_16x16x4_f32 %2, %16, %19, %2\n v_mfma_f32_16x16x4_f32 %3, %16, %20, %3\n")
+                   REP8("v_perm_b32 %4, %4, %21, %22\n ds_read_b32 %12, %21 offset:256\n v_perm_b32 %5, %5, %21, %22\n v_perm_b32 %6, %6, %21, %22\n ds_read_b32 %13, %21 offset:2816\n v_perm_b32 %7, %7, %21, %22\n"
+                        "v_perm_b32 %8, %8, %21, %22\n ds_read_b32 %14, %21 offset:1536\n v_perm_b32 %9, %9, %21, %22\n v_perm_b32 %10, %10, %21, %22\n ds_read_b32 %15, %21 offset:3584\n v_perm_b32 %11, %11, %21, %22\n")
+                   "s_waitcnt lgkmcnt(0)\n"
+                   : "+v"(mc0), "+v"(mc1), "+v"(mc2), "+v"(mc3), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
+                     "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3)
+                   : "v"(m), "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(base32), "s"(sel) : "memory");
+      f4 += g0 + g1 + g2 + g3;
+    } else if constexpr (KIND == K_MFMA_INTER) {
+      float g0, g1, g2, g3;
+      asm volatile(REP8("v_mfma_f32_16x16x4_f32 %0, %16, %17, %0\n v_perm_b32 %4, %4, %21, %22\n v_perm_b32 %5, %5, %21, %22\n ds_read_b32 %12, %21 offset:256\n"
+                        "v_mfma_f32_16x16x4_f32 %1, %16, %18, %1\n v_perm_b32 %6, %6, %21, %22\n v_perm_b32 %7, %7, %21, %22\n ds_read_b32 %13, %21 offset:2816\n"
+                        "v_mfma_f32_16x16x4_f32 %2, %16, %19, %2\n v_perm_b32 %8, %8, %21, %22\n v_perm_b32 %9, %9, %21, %22\n ds_read_b32 %14, %21 offset:1536\n"
+                        "v_mfma_f32_16x16x4_f32 %3, %16, %20, %3\n v_perm_b32 %10, %10, %21, %22\n v_perm_b32 %11, %11, %21, %22\n ds_read_b32 %15, %21 offset:3584\n")
+                   "s_waitcnt lgkmcnt(0)\n"
+                   : "+v"(mc0), "+v"(mc1), "+v"(mc2), "+v"(mc3), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
+                     "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3)
+                   : "v"(m), "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(base32), "s"(sel) : "memory");
+      f4 += g0 + g1 + g2 + g3;
     } else if constexpr (KIND == K_LDSADDF) {
       asm volatile(REP4("ds_add_f32 %0, %1 offset:256\n ds_add_f32 %0, %2 offset:2816\n ds_add_f32 %0, %3 offset:1536\n ds_add_f32 %0, %4 offset:3584\n")
                    "s_waitcnt lgkmcnt(0)\n"
@@ -233,13 +263,21 @@ static void run(unsigned long long* dout, int cus) {
   }
 }
 
-int main() {
+int main(int argc, char** argv) {
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
   printf("device %s, %d CUs\n", prop.name, cus);
   unsigned long long* dout;
   CHECK(hipMalloc(&dout, 2 * cus * 16 * 8));
+  if (argc > 1) {  // "mfma": only the matrix + vector/LDS mixes
+    run<K_OVL_B32>(dout, cus);
+    run<K_MFMA16>(dout, cus);
+    run<K_MFMA_PHASE>(dout, cus);
+    run<K_MFMA_PHASE_PRIO>(dout, cus);
+    run<K_MFMA_INTER>(dout, cus);
+    return 0;
+  }
   run<K_PERM>(dout, cus);
   run<K_ANDOR>(dout, cus);
   run<K_FMA>(dout, cus);
@@ -260,6 +298,9 @@ int main() {
   run<K_MFMA4>(dout, cus);
   run<K_MFMA32>(dout, cus);
   run<K_MFMA16V>(dout, cus);
+  run<K_MFMA_PHASE>(dout, cus);
+  run<K_MFMA_PHASE_PRIO>(dout, cus);
+  run<K_MFMA_INTER>(dout, cus);
   run<K_LDSADDF>(dout, cus);
   run<K_LDSADDU>(dout, cus);
   return 0;
