@@ -71,7 +71,11 @@ typedef struct sqllm_op {
   const int32_t* full_row_indices;  /* [topX]    */
 } sqllm_op;
 
-/* Enqueue one fused kernel computing  mul += W_lut . vec (+ CSR . vec) (+ full_rows^T . vec scattered). */
+/* Enqueue  mul += W_lut . vec (+ CSR . vec) (+ full_rows^T . vec scattered)  on `stream`: one fused
+ * kernel for batch <= 8.  A wider batch ("mfma_min_batch" rows and more) is up to three kernels -- a
+ * transpose of vec into stream-ordered scratch (hipMallocAsync / hipFreeAsync on `stream`; only with
+ * a CSR term, and not while `stream` is capturing), the sparse terms, the dense term on the matrix
+ * cores.  No host synchronisation in either case. */
 int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream);
 
 /* Enqueue `n_ops` ops back to back on `stream` from one host call (a decode pass over a stack of
@@ -252,6 +256,9 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     *_batched ops with cols_min_batch .. cols_max_batch rows (default 2 .. 4; below
  *                     mfma_min_batch) run on the column-lane kernel (lane = output column, vec in
  *                     SGPRs); the other small batches on the batch tiles of the batch-1 kernel
+ *   "sparse_transpose" 1 (default): the CSR term of a wide-batch op reads a transposed copy of vec
+ *                     (lane = batch row, coalesced); 0: it gathers from vec itself, as it does
+ *                     anyway while the stream is capturing or when no scratch can be had
  *   "validate_csr"    debugging aid, default 0.  1 = before every launch that carries a CSR term,
  *                     check ON THE DEVICE that rows[] is non-decreasing with rows[0] == 0 and
  *                     rows[N] == nnz, and return SQLLM_E_SPARSE otherwise.  Blocks the host (one

@@ -26,6 +26,7 @@ struct Knobs {
   std::atomic<int> mfma_min_batch{9};  // *_batched ops with at least this many rows take the matrix-core kernel
   std::atomic<int> cols_min_batch{2};   // *_batched ops with cols_min_batch .. cols_max_batch rows take the column-lane kernel
   std::atomic<int> cols_max_batch{4};   // (measured: ahead of the batch tiles up to 4 rows, behind them at 8)
+  std::atomic<int> sparse_transpose{1};  // wide batches: the CSR role reads a transposed copy of vec (stream-ordered scratch)
   std::atomic<int> validate_csr{0};    // debug: check rows[] on the device before every launch that carries a CSR term
   std::atomic<void*> timeline{nullptr};  // measurement build: per-workgroup timestamp buffer
 };
@@ -238,6 +239,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "mfma_min_batch")) { knobs().mfma_min_batch.store(value < 1 ? 1 : value); return SQLLM_OK; }
   if (!strcmp(name, "cols_min_batch")) { knobs().cols_min_batch.store(value < 1 ? 1 : value); return SQLLM_OK; }
   if (!strcmp(name, "cols_max_batch")) { knobs().cols_max_batch.store(value); return SQLLM_OK; }
+  if (!strcmp(name, "sparse_transpose")) { knobs().sparse_transpose.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { knobs().validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
 #ifdef SQLLM_ABLATION_BUILD
   if (!strcmp(name, "ablate")) { knobs().ablate.store(value); return SQLLM_OK; }
@@ -254,6 +256,7 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "mfma_min_batch")) { *value = knobs().mfma_min_batch.load(); return SQLLM_OK; }
   if (!strcmp(name, "cols_min_batch")) { *value = knobs().cols_min_batch.load(); return SQLLM_OK; }
   if (!strcmp(name, "cols_max_batch")) { *value = knobs().cols_max_batch.load(); return SQLLM_OK; }
+  if (!strcmp(name, "sparse_transpose")) { *value = knobs().sparse_transpose.load(); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { *value = knobs().validate_csr.load(); return SQLLM_OK; }
   return SQLLM_E_OPTION;
 }
@@ -275,7 +278,7 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   plan->dense_blocks = gm.dense_blocks;
   plan->csr_blocks = gm.csr_blocks;
   plan->topx_blocks = gm.topx_blocks;
-  plan->grid_x = gm.dense_block0 + gm.dense_blocks;
+  plan->grid_x = mfma ? gm.dense_blocks : gm.dense_block0 + gm.dense_blocks;  // (wide batches: the sparse terms are a launch of their own)
   const int rows_per_pass = mfma ? 16 * sqllm::mfma_row_blocks(gm.batch) : sqllm::batch_tile(gm.batch);
   plan->grid_y = (gm.batch + rows_per_pass - 1) / rows_per_pass;
   return SQLLM_OK;
@@ -299,6 +302,37 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     // batched operators: one launch per op (the members of a group only share their input) of the
     // matrix-core kernel (wide batches) or of the column-lane kernel (small ones)
     const bool mfma = takes_mfma_path(&ops[0]);
+    // Wide batches with a CSR term: the role wants vec TRANSPOSED (lane = batch row: one coalesced
+    // read per non-zero instead of `batch` gathers).  The copy lives in stream-ordered scratch
+    // (hipMallocAsync / hipFreeAsync on the caller's stream: no host synchronisation, the pool keeps
+    // the block for the next call); skipped while the stream is capturing, where the role falls
+    // back to gathering from vec itself.
+    float* xT = nullptr;
+    int Bp = 0;
+    bool any_csr = false;
+    for (int i = 0; i < n; ++i) any_csr = any_csr || (ops[i].nnz > 0 && ops[i].rows && ops[i].cols && ops[i].vals);
+    if (mfma && any_csr && ops[0].vec && ops[0].batch > 0 && ops[0].K > 0 && knobs().sparse_transpose.load(std::memory_order_relaxed)) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+        Bp = (ops[0].batch + 63) / 64 * 64;
+        void* p = nullptr;
+        if (hipMallocAsync(&p, (size_t)ops[0].K * Bp * sizeof(float), static_cast<hipStream_t>(stream)) == hipSuccess && p) {
+          xT = static_cast<float*>(p);
+          hipError_t e = sqllm::transpose_vec(ops[0].vec, xT, ops[0].batch, ops[0].K, Bp, static_cast<hipStream_t>(stream), e0);
+          if (e == hipSuccess) e0 = nullptr;  // (a profiled group starts with its transpose)
+          if (e != hipSuccess) { (void)hipFreeAsync(p, static_cast<hipStream_t>(stream)); return static_cast<int>(e); }
+        } else {
+          (void)hipGetLastError();  // no scratch: gather from vec
+          Bp = 0;
+        }
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    struct ScratchGuard {
+      float* p; hipStream_t s;
+      ~ScratchGuard() { if (p) (void)hipFreeAsync(p, s); }
+    } guard{xT, static_cast<hipStream_t>(stream)};
     for (int i = 0; i < n; ++i) {
       const sqllm_op* op = &ops[i];
       int rc = validate(op);
@@ -311,6 +345,8 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       a.ev_start = i == 0 ? e0 : nullptr;
       a.ev_stop = i == n - 1 ? e1 : nullptr;
       a.x = op->vec;
+      a.xT = (op->nnz > 0 && op->rows && op->cols && op->vals) ? xT : nullptr;
+      a.Bp = Bp;
       a.ga.n_seg = 1;
       memset(a.ga.seg, 0, sizeof(a.ga.seg));
       sqllm::Segment& sg = a.ga.seg[0];
@@ -326,8 +362,22 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       else make_plan_cols(op, &sg.gm);
       a.ga.block0[0] = 0;
       for (int j = 1; j <= sqllm::kMaxSegments; ++j) a.ga.block0[j] = sg.gm.dense_block0 + sg.gm.dense_blocks;
-      rc = static_cast<int>(mfma ? sqllm::launch_batched_mfma(op->bits, a, static_cast<hipStream_t>(stream))
-                                 : sqllm::launch_batched_cols(op->bits, a, static_cast<hipStream_t>(stream)));
+      if (mfma) {
+        // the sparse terms first, as a launch of their own (see sqllm_sparse_batched), then the dense term
+        // (running the two on different streams was tried: they do not overlap -- the dense kernel holds
+        // every CU's registers -- and the two event waits cost 14 us per op)
+        const bool sparse = sg.gm.csr_blocks + sg.gm.topx_blocks > 0;
+        if (sparse) {
+          sqllm::LaunchArgs as = a;
+          as.ev_stop = nullptr;
+          rc = static_cast<int>(sqllm::launch_batched_sparse(as, static_cast<hipStream_t>(stream)));
+          if (rc != SQLLM_OK) return rc;
+          a.ev_start = nullptr;
+        }
+        rc = static_cast<int>(sqllm::launch_batched_mfma(op->bits, a, static_cast<hipStream_t>(stream)));
+      } else {
+        rc = static_cast<int>(sqllm::launch_batched_cols(op->bits, a, static_cast<hipStream_t>(stream)));
+      }
       if (rc != SQLLM_OK) return rc;
     }
     return SQLLM_OK;

@@ -13,6 +13,7 @@ constexpr int kWaves = SQLLM_WAVES;          // waves per workgroup (512 threads
 constexpr int kTileN = 64;         // output columns per dense tile = 16 lanes x 4 (one dwordx4 each)
 constexpr int kCsrChunk = 1024;    // non-zeros per CSR workgroup
 constexpr int kCsrSpanMax = 2048;  // CSR rows a chunk may span and still accumulate in LDS
+constexpr int kCsrXtSpan = 191;    // ... and still keep a 64-row tile of sums in LDS (wide batches, transposed vec)
 constexpr int kTopxRows = 128;     // k's per top-X slab
 constexpr int kTopxLds = 1024;     // topX up to which slab sums are kept in LDS
 constexpr int kMaxBatchTile = 8;   // batch rows handled per weight pass
@@ -83,6 +84,8 @@ struct LaunchArgs {
   hipEvent_t ev_start = nullptr;  // optional: recorded at this kernel's begin / end (profiling aid)
   hipEvent_t ev_stop = nullptr;
   int ablate = 0;  // measurement builds only (SQLLM_ABLATION_BUILD)
+  const float* xT = nullptr;  // wide-batch launches: transposed copy of x ([K, Bp]) for the CSR role, or null
+  int Bp = 0;
 };
 
 // batch rows handled per weight pass for a given batch size (template instantiations 1/2/4/8)
@@ -94,6 +97,8 @@ inline int mfma_row_blocks(int batch) { return batch <= 16 ? 1 : batch <= 32 ? 2
 hipError_t launch_fused(int bits, const LaunchArgs& a, hipStream_t stream);
 hipError_t launch_batched_mfma(int bits, const LaunchArgs& a, hipStream_t stream);
 hipError_t launch_batched_cols(int bits, const LaunchArgs& a, hipStream_t stream);
+hipError_t transpose_vec(const float* x, float* xT, int batch, int K, int Bp, hipStream_t stream, hipEvent_t ev_start);
+hipError_t launch_batched_sparse(const LaunchArgs& a, hipStream_t stream);
 hipError_t check_csr(const int* rows, int N, int nnz, hipStream_t stream, int* bad);
 
 }  // namespace sqllm

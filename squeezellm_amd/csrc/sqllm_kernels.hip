@@ -1045,11 +1045,12 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
 //   then, LDS only: each non-zero finds its row by binary search in the staged pointers, products
 //   are summed per row in LDS, and each touched row leaves as one atomic.
 // ------------------------------------------------------------------------------------------------
-template <int T, int BT, typename XT, typename AT>
+template <int T, int BT, typename XT, typename AT, bool XTMODE = false>
 __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
                                          const int* __restrict__ rows, const int* __restrict__ cols,
                                          const float* __restrict__ vals, int nnz, int K, int N, int b0,
-                                         int nb, int chunk, float* lds, const Segment* lin, int lin_or_abl_bits = 0) {
+                                         int nb, int chunk, float* lds, const Segment* lin, int lin_or_abl_bits = 0,
+                                         const float* __restrict__ xT = nullptr, int Bp = 0) {
   constexpr bool LIN = sizeof(AT) == 8;
   const int tid = threadIdx.x;
   const int e0 = chunk * kCsrChunk;
@@ -1065,9 +1066,13 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
   constexpr int EPT = kCsrChunk / T;  // non-zeros per thread: e0 + tid + T * i (coalesced)
   int col[EPT];
   float val[EPT];
+  // element of (thread, i): interleaved over the workgroup, or -- transposed-vec mode -- EPT runs of 64
+  // that are consecutive within a wave (so that only a wave's first and last row are shared with its
+  // neighbours)
+  auto elem = [&](int i) { return XTMODE ? e0 + (tid >> 6) * (64 * EPT) + 64 * i + (tid & 63) : e0 + tid + T * i; };
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
-    int e = e0 + tid + T * i;
+    int e = elem(i);
     if (e > e1 - 1) e = e1 - 1;  // clamped re-read; masked below
     col[i] = cols[e];
     val[i] = vals[e];
@@ -1090,7 +1095,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
   // the gather goes out first: the staging loop below waits for its own loads before it stores
   float xg[EPT];
 #pragma unroll
-  for (int i = 0; i < EPT; ++i) xg[i] = (float)x[(size_t)b0 * K + col[i]];  // first batch row's gather
+  for (int i = 0; i < EPT; ++i) xg[i] = XTMODE ? 0.f : (float)x[(size_t)b0 * K + col[i]];  // first batch row's gather
   // Batch rows go through in groups of `g`: as many as have room for their n row sums each in the
   // LDS accumulator (all of them for typical chunks, which span 50-100 rows), so a batched op
   // pays the zero / accumulate / flush round and its barriers once, not once per row, and the x
@@ -1103,13 +1108,19 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
     for (int i = tid; i < n; i += T) srows[i] = rows[c_lo + i];
     for (int i = tid; i < n * g; i += T) sacc[i] = 0.f;  // first group's sums (no barrier of its own)
   }
+  // transposed-vec mode: sums of the pass's rows, tile[row][local column] (odd stride: the lanes of a
+  // wave -- one row each -- write one bank each), zeroed here, flushed coalesced along the columns
+  const bool use_tile = XTMODE && in_lds && n <= kCsrXtSpan;
+  const int TS = n | 1;
+  float* tile = lds + kCsrSpanMax;
+  if (use_tile) for (int i = tid; i < 64 * TS; i += T) tile[i] = 0.f;
   __syncthreads();
 
   // local row of each non-zero: largest i with rows[c_lo + i] <= e
   int lr[EPT];
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
-    const int e = e0 + tid + T * i;
+    const int e = elem(i);
     int lo = 0, hi = n - 1;  // answer in [lo, hi): rows[c_lo + n - 1] > e by construction
     if (hi < 1) hi = 1;
     if (in_lds) {
@@ -1143,6 +1154,73 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
     seg[i] = m;
   }
 
+  if constexpr (XTMODE) {
+    // Wide batches with a TRANSPOSED copy of vec (xT[k][row], written by sqllm_transpose_vec just
+    // before this launch): lane = batch row.  A wave walks its 64 * EPT consecutive non-zeros one
+    // at a time -- column, value and row come out of the owning lane with v_readlane, so control flow
+    // and addresses are scalar -- and every lane loads ITS row's element of xT[k] (one coalesced
+    // read per non-zero instead of one gather per row, 4 K bytes apart) and multiplies.  At the last
+    // non-zero of a row the lanes park their sums in tile[row][column]: a plain store, or an LDS add
+    // for the wave's first and last row (which the neighbouring waves may hold parts of).  The tile
+    // leaves with the lanes along the COLUMNS: coalesced atomics (lanes along the rows would hit
+    // one cache line each: measured 2.1 ms of a 4.6 ms launch at 2048 rows).
+    const int lane = tid & 63;
+    const bool row_ok = lane < nb;
+    const float* xl = xT + (b0 + (row_ok ? lane : 0));
+    unsigned long long ends[EPT], valid[EPT];
+    int n_valid = 0;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      ends[i] = __ballot((seg[i] & 64u) && lr[i] >= 0);
+      valid[i] = __ballot(lr[i] >= 0);
+      n_valid += __builtin_popcountll(valid[i]);
+    }
+#pragma unroll
+    for (int i = 0; i + 1 < EPT; ++i)  // a row that runs on into the next run keeps its sum in the register
+      if ((valid[i + 1] & 1ull) && __builtin_amdgcn_readlane(lr[i], 63) == __builtin_amdgcn_readlane(lr[i + 1], 0)) ends[i] &= ~(1ull << 63);
+    float acc = 0.f;
+    bool first_seg = true;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      constexpr int U = 32;  // loads in flight per wave: the role is latency-bound (a chunk is 1-2 workgroups per CU)
+      for (int j0 = 0; j0 < 64; j0 += U) {
+        if (((valid[i] >> j0) & 1ull) == 0) break;  // (valid lanes are a prefix)
+        float xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = __builtin_amdgcn_readlane(col[i], j0 + u);
+          xv[u] = xl[(size_t)k * Bp];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = j0 + u;
+          const float v = ((valid[i] >> j) & 1ull) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val[i]), j)) : 0.f;
+          acc = __builtin_fmaf(v, xv[u], acc);
+          if ((ends[i] >> j) & 1ull) {
+            const int r = __builtin_amdgcn_readlane(lr[i], j);
+            if (use_tile) {
+              float* slot = tile + lane * TS + r;
+              if (first_seg || 64 * i + j == n_valid - 1) atomicAdd(slot, acc);  // LDS float atomic: lane by lane, twice per wave
+              else *slot = acc;
+            } else if (row_ok) {
+              acc_add(reinterpret_cast<float*>(y) + (size_t)(b0 + lane) * N + c_lo + r, acc);
+            }
+            first_seg = false;
+            acc = 0.f;
+          }
+        }
+      }
+    }
+    if (use_tile) {
+      __syncthreads();
+      const int nm1 = n - 1;
+      for (int idx = tid; idx < nm1 * nb; idx += T) {
+        const int b = idx / nm1, r = idx - b * nm1;
+        const float sum = tile[b * TS + r];
+        if (sum != 0.f) acc_add(reinterpret_cast<float*>(y) + (size_t)(b0 + b) * N + c_lo + r, sum);
+      }
+    }
+  } else {
   const int nm1 = n - 1 > 0 ? n - 1 : 1;
   for (int bs = 0; bs < nb; bs += g) {
     const int gb = nb - bs < g ? nb - bs : g;
@@ -1222,6 +1300,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
       }
     }
   }
+  }  // !XTMODE
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1394,7 +1473,7 @@ constexpr int kXtStride = 36;  // floats per row of a wave's x tile (32 k's + 4:
 constexpr int mfma_codebook_floats(int bits) { return bits == 4 ? 2 * 4096 / 4 : 4 * 8 * 128 / 4; }
 constexpr int mfma_lds_floats(int bits, int mb, int waves) {
   // codebooks, then the waves' x tiles; the epilogue's slabs [waves][16][64] reuse the tile area
-  return cmax(mfma_codebook_floats(bits) + cmax(waves * 16 * mb * kXtStride, waves * 16 * 64), cmax(2 * kCsrSpanMax, kTopxLds));
+  return mfma_codebook_floats(bits) + cmax(waves * 16 * mb * kXtStride, waves * 16 * 64);
 }
 
 template <int BITS, int MB, int WAVES>
@@ -1678,32 +1757,47 @@ __device__ __forceinline__ void dense_role_mfma(const float* __restrict__ x, con
   }  // pieces
 }
 
+// (4-bit, <= 32 rows: two workgroups per CU = 4 waves per SIMD -- the second argument keeps the 32-row kernel at 128 VGPRs)
 template <int BITS, int MB, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
+__global__ void __launch_bounds__(WAVES * 64, (BITS == 4 && MB <= 2 && !(SQLLM_MFMA_VAR & 256)) ? 4 : 1)
 sqllm_fused_batched(const float* x, const GroupArgs ga) {
-  constexpr int T = WAVES * 64;
   __shared__ __attribute__((aligned(16))) float lds[mfma_lds_floats(BITS, MB, WAVES)];
   const Segment& sg = ga.seg[0];
   const KernelGeom& gm = sg.gm;
-  const int bid = blockIdx.x;
   const int m0 = blockIdx.y * 16 * MB;
+  dense_role_mfma<BITS, MB, WAVES>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, gm.batch, m0,
+                                   (int)blockIdx.x, gm.col_tiles, gm.units_total, gm.units_per_wg, lds);
+}
+
+// The sparse terms of a wide-batch op, as a launch of their own: inside the matrix-core kernel the
+// CSR workgroups would inherit its register allocation (one or two workgroups per CU) and run their
+// latency-bound loops without anybody to hide behind -- measured 3.3 ms of a 5.7 ms launch at
+// 2048 rows.  Passes of 64 rows (blockIdx.y); blockIdx.x = CSR chunks, then top-X slabs.
+//   xT != null: the CSR role reads the transposed copy of vec (lane = batch row);
+//   xT == null (no scratch, or the stream is capturing): it gathers from vec, 32 rows at a time.
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+sqllm_sparse_batched(const float* x, const GroupArgs ga, const float* xT, int Bp) {
+  constexpr int T = WAVES * 64;
+  __shared__ __attribute__((aligned(16))) float lds[cmax(kCsrSpanMax + cmax(kCsrSpanMax, 64 * (kCsrXtSpan + 1)), kTopxLds)];
+  const Segment& sg = ga.seg[0];
+  const KernelGeom& gm = sg.gm;
+  const int sp = blockIdx.x;
+  const int m0 = blockIdx.y * 64;
   int rows_here = gm.batch - m0;
-  if (rows_here > 16 * MB) rows_here = 16 * MB;
-  const int d = bid - gm.dense_block0;
-  const int sp = bid < gm.dense_block0 ? bid : -1;
-  if (d >= 0 && d < gm.dense_blocks) {
-    dense_role_mfma<BITS, MB, WAVES>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, d,
-                                     gm.col_tiles, gm.units_total, gm.units_per_wg, lds);
-  } else if (sp >= 0 && sp < gm.csr_blocks) {
-    // the CSR chunk takes the pass's rows 16 (one row block) or 32 at a time: every group of rows costs
-    // the chunk a zero / gather / flush round with its barriers
-    constexpr int CBT = MB == 1 ? 16 : 32;
-    for (int bb = 0; bb < rows_here; bb += CBT) {
-      if (bb) __syncthreads();
-      csr_role<T, CBT, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, m0 + bb,
-                                     rows_here - bb < CBT ? rows_here - bb : CBT, sp, lds, nullptr, 0);
+  if (rows_here > 64) rows_here = 64;
+  if (sp < gm.csr_blocks) {
+    if (xT) {
+      csr_role<T, 1, float, float, true>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, m0, rows_here, sp, lds, nullptr, 0, xT, Bp);
+    } else {
+      constexpr int CBT = 32;  // every group of rows costs the chunk a zero / gather / flush round with its barriers
+      for (int bb = 0; bb < rows_here; bb += CBT) {
+        if (bb) __syncthreads();
+        csr_role<T, CBT, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, m0 + bb,
+                                       rows_here - bb < CBT ? rows_here - bb : CBT, sp, lds, nullptr, 0);
+      }
     }
-  } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
+  } else if (sp < gm.csr_blocks + gm.topx_blocks) {
     topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, m0, rows_here, sp - gm.csr_blocks, lds);
   }
 }
@@ -2095,7 +2189,7 @@ static hipError_t launch_bt(const LaunchArgs& a, hipStream_t stream) {
 template <int BITS, int MB>
 static hipError_t launch_mfma_inst(const LaunchArgs& a, hipStream_t stream) {
   const KernelGeom& gm = a.ga.seg[0].gm;
-  dim3 grid(gm.dense_block0 + gm.dense_blocks, (gm.batch + 16 * MB - 1) / (16 * MB));
+  dim3 grid(gm.dense_blocks, (gm.batch + 16 * MB - 1) / (16 * MB));
   auto kern = sqllm_fused_batched<BITS, MB, kWaves>;
   const float* x = static_cast<const float*>(a.x);
   if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga);
@@ -2138,9 +2232,46 @@ hipError_t launch_batched_cols(int bits, const LaunchArgs& a, hipStream_t stream
   return bits == 4 ? launch_cols_bits<4>(a, stream) : launch_cols_bits<3>(a, stream);
 }
 
-// one op (a.ga.seg[0]), operator ABI, batch rows through the matrix cores
+// the CSR and top-X terms of one wide-batch op (a.ga.seg[0]); a.xT = transposed vec or null
+hipError_t launch_batched_sparse(const LaunchArgs& a, hipStream_t stream) {
+  const KernelGeom& gm = a.ga.seg[0].gm;
+  if (gm.csr_blocks + gm.topx_blocks <= 0) return hipSuccess;
+  dim3 grid(gm.csr_blocks + gm.topx_blocks, (gm.batch + 63) / 64);
+  auto kern = sqllm_sparse_batched<kWaves>;
+  const float* x = static_cast<const float*>(a.x);
+  if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga, a.xT, a.Bp);
+  else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga, a.xT, a.Bp);
+  return hipGetLastError();
+}
+
+// one op (a.ga.seg[0]), operator ABI, batch rows through the matrix cores (dense term only)
 hipError_t launch_batched_mfma(int bits, const LaunchArgs& a, hipStream_t stream) {
   return bits == 4 ? launch_mfma_bits<4>(a, stream) : launch_mfma_bits<3>(a, stream);
+}
+
+// vec [batch, K] -> xT [K, Bp] (Bp = batch rounded up to 64; the padding rows are zeros) for the
+// wide-batch CSR role: 64 x 64 tiles through LDS, reads coalesced along k, writes along the rows.
+__global__ void __launch_bounds__(256) sqllm_transpose_vec(const float* __restrict__ x, float* __restrict__ xT, int batch, int K, int Bp) {
+  __shared__ float tile[64][65];
+  const int k0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + 4 * i, k = k0 + tx;
+    tile[ty + 4 * i][tx] = (r < batch && k < K) ? x[(size_t)r * K + k] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = k0 + ty + 4 * i, r = r0 + tx;
+    if (k < K) xT[(size_t)k * Bp + r] = tile[tx][ty + 4 * i];
+  }
+}
+
+hipError_t transpose_vec(const float* x, float* xT, int batch, int K, int Bp, hipStream_t stream, hipEvent_t ev_start) {
+  if (ev_start) hipExtLaunchKernelGGL(sqllm_transpose_vec, dim3((K + 63) / 64, Bp / 64), dim3(256), 0, stream, ev_start, nullptr, 0, x, xT, batch, K, Bp);
+  else hipLaunchKernelGGL(sqllm_transpose_vec, dim3((K + 63) / 64, Bp / 64), dim3(256), 0, stream, x, xT, batch, K, Bp);
+  return hipGetLastError();
 }
 
 // Debug aid (option "validate_csr"): is `rows` a CSR row-pointer array for nnz values?  The fused

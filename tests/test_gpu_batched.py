@@ -193,3 +193,46 @@ def test_llama65b_shapes_vs_c_oracle(qc, gpu, K, N):
     torch.cuda.synchronize()
     ref = H.c_matvec(H.c_oracle(), case, x, mul, batched=False)
     assert H.rel_err(yt.cpu().numpy(), ref) <= TOL_FP64
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+def test_wide_batch_sparse_term_transposed_or_gathered(qc, gpu, bits):
+    """The CSR term of a wide-batch op reads a transposed copy of vec (default) or gathers from vec
+    itself (option off; also what a capturing stream gets): same result, heavy rows spanning several
+    waves and chunks included."""
+    import torch
+
+    from squeezellm_amd import _lib
+
+    case = H.make_case(bits, 1024, 776, sparse=0.03, topX=6, heavy_rows=3, seed=11)
+    t = H.to_torch(case, gpu)
+    for B in (9, 64, 70, 200):
+        rng = np.random.default_rng(B)
+        x = rng.normal(size=(B, 1024)).astype(np.float32)
+        mul = rng.normal(size=(B, 776)).astype(np.float32)
+        want = H.oracle_ref(case, x, mul, "hybrid")
+        xt = torch.from_numpy(x).to(gpu)
+        try:
+            for flag in (1, 0):
+                _lib.set_option("sparse_transpose", flag)
+                y = torch.from_numpy(mul.copy()).to(gpu)
+                H.call_op(qc, t, xt, y, "hybrid", True)
+                torch.cuda.synchronize()
+                assert H.rel_err(y.cpu().numpy(), want) <= TOL_FP64, (B, flag)
+        finally:
+            _lib.set_option("sparse_transpose", 1)
+        # captured: no scratch allocation inside the capture, the role gathers
+        y = torch.from_numpy(mul.copy()).to(gpu)
+        ystat = y.clone()
+        s = torch.cuda.Stream(device=gpu)
+        s.wait_stream(torch.cuda.current_stream(gpu))
+        with torch.cuda.stream(s):
+            H.call_op(qc, t, xt, ystat.clone(), "hybrid", True)  # warm-up outside the capture
+        torch.cuda.current_stream(gpu).wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            H.call_op(qc, t, xt, ystat, "hybrid", True)
+        ystat.copy_(y)
+        g.replay()
+        torch.cuda.synchronize()
+        assert H.rel_err(ystat.cpu().numpy(), want) <= TOL_FP64, (B, "graph")

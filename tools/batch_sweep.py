@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--topx", type=int, default=10)
     ap.add_argument("--batches", default="1,2,4,8,16,32,64,128")
     ap.add_argument("--paths", default="tile,cols,mfma")
+    ap.add_argument("--sparse-transpose", type=int, default=1, help="0: the wide-batch CSR role gathers from vec itself")
     ap.add_argument("--total-mb", type=float, default=600.0)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--check", action="store_true", help="parity of the matrix-core path vs the oracle on a small shape")
@@ -33,6 +34,7 @@ def main():
     from squeezellm_amd import _lib, decode, quant_cuda as qc, synth
 
     dev = torch.device("cuda:0")
+    _lib.set_option("sparse_transpose", args.sparse_transpose)
     if args.check:
         import helpers as H
 
@@ -76,9 +78,17 @@ def main():
             seq = decode.OpSequence(layers, xs, ys, batched=True)
             seq.profile(reps=1)
             us = seq.profile(reps=args.reps)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(args.reps):
+                seq.launch()  # wall time per op, everything the call enqueues included (vec transpose, scratch)
+            ev1.record()
+            torch.cuda.synchronize()
+            wall = ev0.elapsed_time(ev1) * 1e3 / (args.reps * len(layers))
             plan = _lib.plan_query(args.bits, K, N, B, nnz=layers[0]["vals"].numel() if args.sparse else 0, topX=args.topx if args.sparse else 0)
             print(json.dumps(dict(shape=args.shape, bits=args.bits, batch=B, path=path, grid=[plan["grid_x"], plan["grid_y"]], k_slices=plan["k_slices"],
-                                  us_mean=round(float(us.mean()), 2), us_min=round(float(us.min()), 2), GBps=round(nbytes / us.mean() / 1e3, 1),
+                                  us_mean=round(float(us.mean()), 2), us_min=round(float(us.min()), 2), wall_us=round(wall, 2), GBps=round(nbytes / us.mean() / 1e3, 1),
                                   TFLOPs=round(2.0 * B * K * N / us.mean() / 1e6, 2))), flush=True)
         del xs, ys
 
