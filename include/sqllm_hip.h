@@ -250,12 +250,12 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *   "groups_per_wave" force the K units each wave walks (default 0 = derived from target_wgs)
  *   "sparse_last"     1 = CSR / top-X workgroups after the dense ones in the grid (default 0)
  *   "cu_count"        override the CU count used for planning (GPU-less tests)
- *   "mfma_min_batch"  *_batched ops with at least this many rows run on the fp32 matrix cores
- *                     (default 9: the 8-row batch tiles serve smaller batches in one pass)
- *   "cols_min_batch", "cols_max_batch"
- *                     *_batched ops with cols_min_batch .. cols_max_batch rows (default 2 .. 4; below
- *                     mfma_min_batch) run on the column-lane kernel (lane = output column, vec in
- *                     SGPRs); the other small batches on the batch tiles of the batch-1 kernel
+ *   "mfma_min_batch", "cols_min_batch", "cols_max_batch"
+ *                     routing of the *_batched operators by batch size: cols_min_batch .. cols_max_batch
+ *                     rows run on the column-lane kernel (lane = output column, vec in SGPRs),
+ *                     mfma_min_batch rows and more on the fp32 matrix cores, everything else on the
+ *                     batch tiles of the batch-1 kernel.  Defaults (value 0 = measured default, which
+ *                     depends on the bit width): 4-bit 2..4 / 9, 3-bit 2..16 / 17.
  *   "sparse_transpose" 1 (default): the CSR term of a wide-batch op reads a transposed copy of vec
  *                     (lane = batch row, coalesced); 0: it gathers from vec itself, as it does
  *                     anyway while the stream is capturing or when no scratch can be had

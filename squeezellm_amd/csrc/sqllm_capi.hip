@@ -23,9 +23,13 @@ struct Knobs {
   std::atomic<int> ablate{0};
   std::atomic<int> sparse_last{0};
   std::atomic<int> ablate_csr{0};
-  std::atomic<int> mfma_min_batch{9};  // *_batched ops with at least this many rows take the matrix-core kernel
-  std::atomic<int> cols_min_batch{2};   // *_batched ops with cols_min_batch .. cols_max_batch rows take the column-lane kernel
-  std::atomic<int> cols_max_batch{4};   // (measured: ahead of the batch tiles up to 4 rows, behind them at 8)
+  // Routing of the *_batched operators by batch size (0 = the measured defaults, which depend on the bit width:
+  // 13B gate/up shape, profiles/r02_batch_paths_*.txt):
+  //   4-bit: 2..4 rows column-lane kernel, 5..8 batch tiles of the batch-1 kernel, 9+ matrix cores
+  //   3-bit: 2..16 rows column-lane kernel (two passes from 9 rows), 17+ matrix cores
+  std::atomic<int> mfma_min_batch{0};  // rows from which the matrix-core kernel takes over
+  std::atomic<int> cols_min_batch{2};  // the column-lane kernel serves cols_min_batch .. cols_max_batch rows
+  std::atomic<int> cols_max_batch{0};
   std::atomic<int> sparse_transpose{1};  // wide batches: the CSR role reads a transposed copy of vec (stream-ordered scratch)
   std::atomic<int> validate_csr{0};    // debug: check rows[] on the device before every launch that carries a CSR term
   std::atomic<void*> timeline{nullptr};  // measurement build: per-workgroup timestamp buffer
@@ -167,9 +171,16 @@ void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm) {
   gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
 }
 
-bool takes_mfma_path(const sqllm_op* op) {
-  return op->batch >= 1 && op->batch >= knobs().mfma_min_batch.load(std::memory_order_relaxed);
+int mfma_min_batch_of(const sqllm_op* op) {
+  const int v = knobs().mfma_min_batch.load(std::memory_order_relaxed);
+  return v > 0 ? v : (op->bits == 3 ? 17 : 9);
 }
+int cols_max_batch_of(const sqllm_op* op) {
+  const int v = knobs().cols_max_batch.load(std::memory_order_relaxed);
+  return v > 0 ? v : (op->bits == 3 ? 16 : 4);
+}
+
+bool takes_mfma_path(const sqllm_op* op) { return op->batch >= 1 && op->batch >= mfma_min_batch_of(op); }
 
 // Geometry of the small-batch column-lane kernel: passes of batch_tile(batch) <= 8 rows
 // (blockIdx.y); the dense work of a pass is cut into equal ranges of the flattened
@@ -199,7 +210,7 @@ void make_plan_cols(const sqllm_op* op, sqllm::KernelGeom* gm) {
 
 bool takes_cols_path(const sqllm_op* op) {
   return !takes_mfma_path(op) && op->batch >= 1 && op->batch >= knobs().cols_min_batch.load(std::memory_order_relaxed) &&
-         op->batch <= knobs().cols_max_batch.load(std::memory_order_relaxed);
+         op->batch <= cols_max_batch_of(op);
 }
 
 }  // namespace
@@ -236,7 +247,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "groups_per_wave")) { knobs().groups_per_wave.store(value); return SQLLM_OK; }
   if (!strcmp(name, "sparse_last")) { knobs().sparse_last.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { knobs().cu_count.store(value); return SQLLM_OK; }  // for GPU-less planning tests
-  if (!strcmp(name, "mfma_min_batch")) { knobs().mfma_min_batch.store(value < 1 ? 1 : value); return SQLLM_OK; }
+  if (!strcmp(name, "mfma_min_batch")) { knobs().mfma_min_batch.store(value); return SQLLM_OK; }
   if (!strcmp(name, "cols_min_batch")) { knobs().cols_min_batch.store(value < 1 ? 1 : value); return SQLLM_OK; }
   if (!strcmp(name, "cols_max_batch")) { knobs().cols_max_batch.store(value); return SQLLM_OK; }
   if (!strcmp(name, "sparse_transpose")) { knobs().sparse_transpose.store(value ? 1 : 0); return SQLLM_OK; }
