@@ -309,7 +309,10 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
                                     hipEvent_t e1, const sqllm_linear* lin = nullptr) {
   if (n < 1 || n > sqllm::kMaxSegments) return SQLLM_E_GROUP;
   if (!ops && !lin) return SQLLM_E_NULL;
-  if (!lin && (takes_mfma_path(&ops[0]) || takes_cols_path(&ops[0]))) {
+  // (the column-lane kernel only for an op that is alone in its launch: q/k/v or gate/up sharing one
+  // launch of the batch tiles beat three / two launches of it -- 13B s45 decoder layer at 2 rows:
+  // 88 vs 101 us)
+  if (!lin && (takes_mfma_path(&ops[0]) || (n == 1 && takes_cols_path(&ops[0])))) {
     // batched operators: one launch per op (the members of a group only share their input) of the
     // matrix-core kernel (wide batches) or of the column-lane kernel (small ones)
     const bool mfma = takes_mfma_path(&ops[0]);

@@ -32,4 +32,19 @@ run pmc_sq --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTI
 sum /tmp/prof_pmc_sq > $R/gpurun_out/${tag}_pmc_sq.summary.txt
 run pmc_sq_waits --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_ADDR_CONFLICT --kernel-trace -d /tmp/prof_pmc_sq_waits -o x -- python $R/bench.py --steps 3 --warmup 1 --launch sequence --no-cpu-baseline --no-sub-records --no-roofline --repeats 1 --layers 8
 sum /tmp/prof_pmc_sq_waits > $R/gpurun_out/${tag}_pmc_sq_waits.summary.txt
+# wide-batch (matrix-core) path: 13B gate/up shape, hybrid, 16 and 2048 rows
+run kt_batched --kernel-trace --stats -d /tmp/prof_kt_batched -o x -- python $R/tools/batch_sweep.py --paths mfma --batches 16,2048 --reps 2
+sum /tmp/prof_kt_batched > $R/gpurun_out/${tag}_kt_batched.summary.txt
+grep '^{' /tmp/prof_kt_batched.log >> $R/gpurun_out/${tag}_kt_batched.summary.txt
+run pmc_batched_fetch --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_pmc_batched_fetch -o x -- python $R/tools/batch_sweep.py --paths mfma --batches 16,2048 --reps 1
+sum /tmp/prof_pmc_batched_fetch > $R/gpurun_out/${tag}_pmc_batched_fetch.summary.txt
+run pmc_batched_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace -d /tmp/prof_pmc_batched_mfma -o x -- python $R/tools/batch_sweep.py --paths mfma --batches 16,2048 --reps 1 --sparse 0 --topx 0
+sum /tmp/prof_pmc_batched_mfma > $R/gpurun_out/${tag}_pmc_batched_mfma.summary.txt
+# un-profiled bench lines, all configs, one box
+cd $R
+for c in 7b-w4-s0 7b-w3-s45 7b-w4-s45 7b-w3-s0 13b-w4-s45 65b-w3-s45; do
+  extra="--no-sub-records"; [ $c = 7b-w4-s0 ] && extra=""
+  timeout 400 python bench.py --config $c $extra 2>/dev/null | grep '^{' > gpurun_out/${tag}_bench_$c.json
+done
+timeout 300 python bench.py --no-fuse --no-sub-records --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${tag}_bench_7b-w4-s0_unfused.json
 ls -la $R/gpurun_out/ | grep ${tag}_
