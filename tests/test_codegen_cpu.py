@@ -80,3 +80,65 @@ def test_three_bit_batch1_decode_uses_pair_lookups(asm):
         pk = sum(1 for l in body if re.match(r"\s+v_pk_fma_f32", l))
         assert b64 >= 128 and pk >= 128, (name, b64, pk)  # two copies of the step (first chunk + loop) x 64
         assert b32 <= 16, (name, b32)                       # epilogue / sparse roles only
+
+
+# ---- round 2: the batched kernel families ----
+
+def _family(asm, mangled_prefix):
+    out = {}
+    for m in re.finditer(r"^(" + mangled_prefix + r"\w+):.*?^\.Lfunc_end", asm, re.S | re.M):
+        out[m.group(1)] = m.group(0).split("\n")
+    return out
+
+
+def _meta(asm, mangled_prefix):
+    return re.findall(r"\.name:\s+(" + mangled_prefix + r"\w+).*?\.private_segment_fixed_size:\s+(\d+).*?"
+                      r"\.sgpr_spill_count:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", asm, re.S)
+
+
+def test_column_lane_kernels(asm):
+    """lane = column, vec in SGPRs: the x operands of the packed FMAs must be SGPR pairs fed by scalar loads
+    with an SGPR offset (the compiler's own pointer arithmetic once cost two v_readlane per load), no
+    FLAT, no scratch, <= 80 VGPRs (three 8-wave workgroups per CU)."""
+    ks = _family(asm, "_ZN5sqllm16sqllm_fused_cols")
+    assert len(ks) == 8  # {3,4} bits x batch tile {1,2,4,8}
+    for name, body in ks.items():
+        assert not [l for l in body if re.match(r"\s+flat_", l)], name
+        pk = [l for l in body if re.match(r"\s+v_pk_fma_f32", l)]
+        assert pk and all(re.search(r"v_pk_fma_f32 v\[\d+:\d+\], v\[\d+:\d+\], s\[\d+:\d+\], v\[\d+:\d+\]", l) for l in pk), name
+        sload = [l for l in body if re.match(r"\s+s_load_dwordx[48] s\[\d+:\d+\], s\[\d+:\d+\], s\d+", l)]
+        bt = int(re.search(r"colsILi[34]ELi(\d)E", name).group(1))
+        assert len(sload) >= 2 * bt, (name, len(sload))
+        assert [l for l in body if "buffer_load_dword" in l], name  # range-checked weight loads
+    for name, scratch, sspill, vgpr, vspill in _meta(asm, "_ZN5sqllm16sqllm_fused_cols"):
+        assert int(scratch) == 0 and int(vspill) == 0 and int(vgpr) <= 80, (name, scratch, vspill, vgpr)
+
+
+def test_matrix_core_kernels(asm):
+    """fp32 MFMA kernels: 32 matrix instructions per decoded group and row block, no FLAT, no LDS float
+    atomics in the epilogue (ds_add_f32 executes lane by lane: 50 us per launch once), register budgets of
+    the measured occupancy (two workgroups per CU up to 32 rows for 4-bit)."""
+    ks = _family(asm, "_ZN5sqllm19sqllm_fused_batched")
+    assert len(ks) == 6  # {3,4} bits x {1,2,4} row blocks
+    for name, body in ks.items():
+        assert not [l for l in body if re.match(r"\s+flat_", l)], name
+        assert not [l for l in body if re.match(r"\s+ds_add_(rtn_)?f32", l)], name
+        mb = int(re.search(r"batchedILi[34]ELi(\d)E", name).group(1))
+        n_mfma = sum(1 for l in body if "v_mfma_f32_16x16x4_f32" in l or "v_mfma_f32_16x16x4f32" in l)
+        assert n_mfma >= 64 * mb, (name, n_mfma)
+    budget = {(4, 1): 104, (4, 2): 128, (4, 4): 224, (3, 1): 128, (3, 2): 176, (3, 4): 256}
+    for name, scratch, sspill, vgpr, vspill in _meta(asm, "_ZN5sqllm19sqllm_fused_batched"):
+        bits, mb = map(int, re.search(r"batchedILi([34])ELi(\d)E", name).groups())
+        assert int(vgpr) <= budget[(bits, mb)], (name, vgpr)
+        if (bits, mb) not in ((4, 2), (3, 4)):  # (these two trade a few spilled dwords for their occupancy)
+            assert int(scratch) == 0 and int(vspill) == 0, (name, scratch, vspill)
+
+
+def test_wide_batch_sparse_kernel(asm):
+    ks = _family(asm, "_ZN5sqllm20sqllm_sparse_batched")
+    assert len(ks) == 1
+    for name, body in ks.items():
+        assert not [l for l in body if re.match(r"\s+flat_", l)], name
+        assert [l for l in body if "v_readlane_b32" in l], name  # scalar walk over the non-zeros
+    for name, scratch, sspill, vgpr, vspill in _meta(asm, "_ZN5sqllm20sqllm_sparse_batched"):
+        assert int(scratch) == 0 and int(vspill) == 0 and int(vgpr) <= 128, (name, scratch, vspill, vgpr)
