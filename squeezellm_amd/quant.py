@@ -134,16 +134,18 @@ class QuantLinearLUTFused(QuantLinearLUT):
     parent's path."""
 
     def _workspace(self, batch: int, device) -> torch.Tensor:
-        """ONE zero-filled workspace per device, sized for the largest batch seen so far: a launch
-        uses the first 8 * batch * N bytes and leaves them zero-filled, so smaller batches reuse
-        the same buffer (a cache keyed by batch size would grow without bound under variable
-        prompt lengths)."""
+        """ONE zero-filled workspace per (device, stream), sized for the largest batch seen so far: a
+        launch uses the first 8 * batch * N bytes and leaves them zero-filled, so smaller batches
+        reuse the same buffer (a cache keyed by batch size would grow without bound under variable
+        prompt lengths).  Two launches of one module that may overlap -- i.e. on different streams --
+        must not share the accumulator words, hence the stream in the key."""
         cache = self.__dict__.setdefault("_ws", {})
         need = _lib.linear_workspace_bytes(self.outfeatures, batch)
-        ws = cache.get(device)
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        ws = cache.get(key)
         if ws is None or ws.numel() < need:
             ws = torch.zeros(need, dtype=torch.uint8, device=device)  # zero-filled once
-            cache[device] = ws
+            cache[key] = ws
         return ws
 
     def _check_csr_once(self) -> None:

@@ -3,7 +3,7 @@
     python tools/linear_overhead.py
 """
 import sys, os, json, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from squeezellm_amd import decode, synth
 dev = torch.device("cuda:0")
