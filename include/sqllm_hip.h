@@ -74,8 +74,9 @@ typedef struct sqllm_op {
 /* Enqueue  mul += W_lut . vec (+ CSR . vec) (+ full_rows^T . vec scattered)  on `stream`: one fused
  * kernel for batch <= 8.  A wider batch ("mfma_min_batch" rows and more) is up to three kernels -- a
  * transpose of vec into stream-ordered scratch (hipMallocAsync / hipFreeAsync on `stream`; only with
- * a CSR term, and not while `stream` is capturing), the sparse terms, the dense term on the matrix
- * cores.  No host synchronisation in either case. */
+ * a CSR term; inside a stream capture they become memory nodes of the graph unless option
+ * "scratch_in_capture" is 0), the sparse terms, the dense term on the matrix cores.  No host
+ * synchronisation in either case. */
 int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream);
 
 /* Enqueue `n_ops` ops back to back on `stream` from one host call (a decode pass over a stack of
@@ -258,7 +259,8 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     depends on the bit width): 4-bit 2..4 / 9, 3-bit 2..16 / 17.
  *   "sparse_transpose" 1 (default): the CSR term of a wide-batch op reads a transposed copy of vec
  *                     (lane = batch row, coalesced); 0: it gathers from vec itself, as it does
- *                     anyway while the stream is capturing or when no scratch can be had
+ *                     anyway when no scratch can be had
+ *   "scratch_in_capture" 1 (default): that scratch is also taken while the stream is capturing
  *   "validate_csr"    debugging aid, default 0.  1 = before every launch that carries a CSR term,
  *                     check ON THE DEVICE that rows[] is non-decreasing with rows[0] == 0 and
  *                     rows[N] == nnz, and return SQLLM_E_SPARSE otherwise.  Blocks the host (one

@@ -30,6 +30,7 @@ struct Knobs {
   std::atomic<int> mfma_min_batch{0};  // rows from which the matrix-core kernel takes over
   std::atomic<int> cols_min_batch{2};  // the column-lane kernel serves cols_min_batch .. cols_max_batch rows
   std::atomic<int> cols_max_batch{0};
+  std::atomic<int> scratch_in_capture{1};  // stream-ordered scratch also while the stream is capturing (graph memory nodes)
   std::atomic<int> sparse_transpose{1};  // wide batches: the CSR role reads a transposed copy of vec (stream-ordered scratch)
   std::atomic<int> validate_csr{0};    // debug: check rows[] on the device before every launch that carries a CSR term
   std::atomic<void*> timeline{nullptr};  // measurement build: per-workgroup timestamp buffer
@@ -251,6 +252,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "cols_min_batch")) { knobs().cols_min_batch.store(value < 1 ? 1 : value); return SQLLM_OK; }
   if (!strcmp(name, "cols_max_batch")) { knobs().cols_max_batch.store(value); return SQLLM_OK; }
   if (!strcmp(name, "sparse_transpose")) { knobs().sparse_transpose.store(value ? 1 : 0); return SQLLM_OK; }
+  if (!strcmp(name, "scratch_in_capture")) { knobs().scratch_in_capture.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { knobs().validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
 #ifdef SQLLM_ABLATION_BUILD
   if (!strcmp(name, "ablate")) { knobs().ablate.store(value); return SQLLM_OK; }
@@ -268,6 +270,7 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "cols_min_batch")) { *value = knobs().cols_min_batch.load(); return SQLLM_OK; }
   if (!strcmp(name, "cols_max_batch")) { *value = knobs().cols_max_batch.load(); return SQLLM_OK; }
   if (!strcmp(name, "sparse_transpose")) { *value = knobs().sparse_transpose.load(); return SQLLM_OK; }
+  if (!strcmp(name, "scratch_in_capture")) { *value = knobs().scratch_in_capture.load(); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { *value = knobs().validate_csr.load(); return SQLLM_OK; }
   return SQLLM_E_OPTION;
 }
@@ -319,15 +322,20 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     // Wide batches with a CSR term: the role wants vec TRANSPOSED (lane = batch row: one coalesced
     // read per non-zero instead of `batch` gathers).  The copy lives in stream-ordered scratch
     // (hipMallocAsync / hipFreeAsync on the caller's stream: no host synchronisation, the pool keeps
-    // the block for the next call); skipped while the stream is capturing, where the role falls
-    // back to gathering from vec itself.
+    // the block for the next call).  Without scratch the role falls back to gathering from vec itself.
     float* xT = nullptr;
     int Bp = 0;
     bool any_csr = false;
     for (int i = 0; i < n; ++i) any_csr = any_csr || (ops[i].nnz > 0 && ops[i].rows && ops[i].cols && ops[i].vals);
     if (mfma && any_csr && ops[0].vec && ops[0].batch > 0 && ops[0].K > 0 && knobs().sparse_transpose.load(std::memory_order_relaxed)) {
-      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+      // (inside a stream capture the allocation and the free become memory nodes of the graph -- works under
+      // torch's graph capture on ROCm 7.2; option scratch_in_capture = 0 keeps captures allocation-free)
+      bool scratch_ok = true;
+      if (!knobs().scratch_in_capture.load(std::memory_order_relaxed)) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        scratch_ok = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+      }
+      if (scratch_ok) {
         Bp = (ops[0].batch + 63) / 64 * 64;
         void* p = nullptr;
         if (hipMallocAsync(&p, (size_t)ops[0].K * Bp * sizeof(float), static_cast<hipStream_t>(stream)) == hipSuccess && p) {

@@ -221,18 +221,25 @@ def test_wide_batch_sparse_term_transposed_or_gathered(qc, gpu, bits):
                 assert H.rel_err(y.cpu().numpy(), want) <= TOL_FP64, (B, flag)
         finally:
             _lib.set_option("sparse_transpose", 1)
-        # captured: no scratch allocation inside the capture, the role gathers
-        y = torch.from_numpy(mul.copy()).to(gpu)
-        ystat = y.clone()
-        s = torch.cuda.Stream(device=gpu)
-        s.wait_stream(torch.cuda.current_stream(gpu))
-        with torch.cuda.stream(s):
-            H.call_op(qc, t, xt, ystat.clone(), "hybrid", True)  # warm-up outside the capture
-        torch.cuda.current_stream(gpu).wait_stream(s)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            H.call_op(qc, t, xt, ystat, "hybrid", True)
-        ystat.copy_(y)
-        g.replay()
-        torch.cuda.synchronize()
-        assert H.rel_err(ystat.cpu().numpy(), want) <= TOL_FP64, (B, "graph")
+        # captured, with the scratch as graph memory nodes (default) and without (the role gathers)
+        try:
+            for in_capture in (1, 0):
+                _lib.set_option("scratch_in_capture", in_capture)
+                y = torch.from_numpy(mul.copy()).to(gpu)
+                ystat = y.clone()
+                s = torch.cuda.Stream(device=gpu)
+                s.wait_stream(torch.cuda.current_stream(gpu))
+                with torch.cuda.stream(s):
+                    H.call_op(qc, t, xt, ystat.clone(), "hybrid", True)  # warm-up outside the capture
+                torch.cuda.current_stream(gpu).wait_stream(s)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    H.call_op(qc, t, xt, ystat, "hybrid", True)
+                ystat.copy_(y)
+                g.replay()
+                g.replay()  # (the graph owns its scratch: replays must not interfere; mul accumulates twice)
+                torch.cuda.synchronize()
+                want2 = H.oracle_ref(case, x, want, "hybrid")
+                assert H.rel_err(ystat.cpu().numpy(), want2) <= TOL_FP64, (B, "graph", in_capture)
+        finally:
+            _lib.set_option("scratch_in_capture", 1)
