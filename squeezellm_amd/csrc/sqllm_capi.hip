@@ -266,6 +266,7 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "target_wgs")) { *value = knobs().target_wgs.load(); return SQLLM_OK; }
   if (!strcmp(name, "groups_per_wave")) { *value = knobs().groups_per_wave.load(); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { *value = knobs().cu_count.load(); return SQLLM_OK; }
+  if (!strcmp(name, "sparse_last")) { *value = knobs().sparse_last.load(); return SQLLM_OK; }
   if (!strcmp(name, "mfma_min_batch")) { *value = knobs().mfma_min_batch.load(); return SQLLM_OK; }
   if (!strcmp(name, "cols_min_batch")) { *value = knobs().cols_min_batch.load(); return SQLLM_OK; }
   if (!strcmp(name, "cols_max_batch")) { *value = knobs().cols_max_batch.load(); return SQLLM_OK; }

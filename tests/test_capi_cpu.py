@@ -245,3 +245,27 @@ print("OK")
 ''' % H.ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stderr[-2000:]
+
+
+def test_every_documented_option_round_trips():
+    """Each option name the header documents is accepted by set / get (per device: slot 0 without a GPU),
+    and the defaults are the documented ones."""
+    import re
+
+    from squeezellm_amd import _lib
+
+    hdr = open(HEADER).read()
+    block = hdr[hdr.index("Launch-geometry knobs"):hdr.index("int sqllm_set_option")]
+    names = sorted(set(re.findall(r'"([a-z_]+)"', block)))
+    assert {"target_wgs", "groups_per_wave", "sparse_last", "cu_count", "mfma_min_batch", "cols_min_batch", "cols_max_batch",
+            "sparse_transpose", "scratch_in_capture", "validate_csr"} <= set(names)
+    defaults = {"mfma_min_batch": 0, "cols_min_batch": 2, "cols_max_batch": 0, "sparse_transpose": 1, "scratch_in_capture": 1,
+                "validate_csr": 0, "sparse_last": 0, "target_wgs": 0, "groups_per_wave": 0}
+    for n in names:
+        before = _lib.get_option(n)
+        if n in defaults:
+            assert before == defaults[n], (n, before)
+        _lib.set_option(n, 1)
+        assert _lib.get_option(n) == 1, n
+        _lib.set_option(n, before)
+        assert _lib.get_option(n) == before, n
