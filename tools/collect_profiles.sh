@@ -40,6 +40,9 @@ run pmc_batched_fetch --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_pmc_batched_f
 sum /tmp/prof_pmc_batched_fetch > $R/gpurun_out/${tag}_pmc_batched_fetch.summary.txt
 run pmc_batched_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace -d /tmp/prof_pmc_batched_mfma -o x -- python $R/tools/batch_sweep.py --paths mfma --batches 16,2048 --reps 1 --sparse 0 --topx 0
 sum /tmp/prof_pmc_batched_mfma > $R/gpurun_out/${tag}_pmc_batched_mfma.summary.txt
+# small batches: batch tiles vs column-lane kernel, 13B gate/up shape, dense and hybrid
+run kt_small_batches --kernel-trace --stats -d /tmp/prof_kt_small -o x -- python $R/tools/batch_sweep.py --paths tile,cols --batches 2,4,8 --reps 2 --sparse 0 --topx 0
+sum /tmp/prof_kt_small > $R/gpurun_out/${tag}_kt_small_batches.summary.txt
 # un-profiled bench lines, all configs, one box
 cd $R
 for c in 7b-w4-s0 7b-w3-s45 7b-w4-s45 7b-w3-s0 13b-w4-s45 65b-w3-s45; do
