@@ -256,22 +256,31 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     rows run on the column-lane kernel (lane = output column, vec in SGPRs),
  *                     mfma_min_batch rows and more on the fp32 matrix cores, everything else on the
  *                     batch tiles of the batch-1 kernel.  Defaults (value 0 = measured default, which
- *                     depends on the bit width): 4-bit 2..4 / 9, 3-bit 2..16 / 17.
+ *                     depends on the bit width; get_option returns the stored 0): 4-bit 2..4 / 9, 3-bit 2..16 / 17.
  *   "sparse_transpose" 1 (default): the CSR term of a wide-batch op reads a transposed copy of vec
  *                     (lane = batch row, coalesced); 0: it gathers from vec itself, as it does
  *                     anyway when no scratch can be had
- *   "scratch_in_capture" 1 (default): that scratch is also taken while the stream is capturing
+ *                     The scratch is stream-ordered (hipMallocAsync / hipFreeAsync on the caller's
+ *                     stream, K x ceil64(batch) floats per op or group); on first use per device the
+ *                     library raises the release threshold of the device's DEFAULT memory pool to
+ *                     256 MiB (never lowers it) so that the block survives synchronisations.
+ *   "scratch_in_capture" 1 (default): that scratch is also taken while the stream is capturing --
+ *                     a captured wide-batch op with a CSR term then carries a memory-allocation
+ *                     and a memory-free node in the graph; 0 keeps captures allocation-free (the
+ *                     CSR term gathers from vec instead)
  *   "validate_csr"    debugging aid, default 0.  1 = before every launch that carries a CSR term,
  *                     check ON THE DEVICE that rows[] is non-decreasing with rows[0] == 0 and
  *                     rows[N] == nnz, and return SQLLM_E_SPARSE otherwise.  Blocks the host (one
- *                     tiny kernel, a 4-byte read-back, a stream synchronise; 4 bytes of device
- *                     memory are allocated on first use); skipped while the stream is capturing.
+ *                     tiny kernel, a 4-byte read-back, a stream synchronise; 4 bytes of stream-ordered
+ *                     scratch on the current device per check); skipped while the stream is capturing.
  *                     Meant for the fused linear, which counts on `rows` to detect completion.
  * Returns SQLLM_E_OPTION for an unknown name. */
 int sqllm_set_option(const char* name, int value);
 int sqllm_get_option(const char* name, int* value);
 
-/* Geometry the library would use for a dense op of this shape (for tests and DESIGN.md tables). */
+/* Geometry the library would use for this op launched ALONE (sqllm_launch / the operator names).  Ops
+ * that share a launch (sqllm_launch_group) are planned with other workgroup counts, and the
+ * column-lane kernel is only taken by an op that is alone in its launch. */
 typedef struct sqllm_plan {
   int32_t col_tiles, k_slices, groups_per_wave, dense_blocks, csr_blocks, topx_blocks, grid_x, grid_y;
 } sqllm_plan;

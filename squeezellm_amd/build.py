@@ -5,6 +5,7 @@ No torch headers, no pybind11: the product is a plain C-ABI shared library (incl
 built in-tree next to this file, so it travels with the source tree.
 
     python -m squeezellm_amd.build [--force] [--verbose]
+    python -m squeezellm_amd.build --ablation [--out PATH]     # measurement build, separate library
 """
 from __future__ import annotations
 
@@ -25,10 +26,18 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
+class HipccMissing(RuntimeError):
+    """No hipcc on this host: the library cannot be built here (and there is no fallback)."""
+
+
+class BuildError(RuntimeError):
+    """hipcc ran and failed: the sources do not compile."""
+
+
 def hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
-        raise RuntimeError("hipcc not found: the MI355X kernels cannot be built (no fallback exists)")
+        raise HipccMissing("hipcc not found: the MI355X kernels cannot be built (no fallback exists)")
     return exe
 
 
@@ -40,38 +49,55 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/*.hip -> squeezellm_amd/libsqllm_hip.so (cross-compiles without a GPU).
-    SQLLM_ABLATION=1 in the environment adds the measurement-only ablation kernel variants."""
-    if not force and not is_stale():
-        return LIB_PATH
-    extra = ["-DSQLLM_ABLATION_BUILD"] if os.environ.get("SQLLM_ABLATION") == "1" else []
-    if os.environ.get("SQLLM_WAVES"):  # measurement builds: waves per workgroup (default 8)
-        extra.append("-DSQLLM_WAVES=" + str(int(os.environ["SQLLM_WAVES"])))
-    if os.environ.get("SQLLM_PAIR3"):  # measurement builds: 0 = 3-bit decode with one lookup per weight
-        extra.append("-DSQLLM_PAIR3=" + str(int(os.environ["SQLLM_PAIR3"])))
-    if os.environ.get("SQLLM_HALF_STAGES"):  # measurement builds: 0 = whole-stage decode (32 live lookups)
-        extra.append("-DSQLLM_HALF_STAGES=" + str(int(os.environ["SQLLM_HALF_STAGES"])))
-    if os.environ.get("SQLLM_PAIR3_NOCONFLICT"):  # measurement builds (wrong results): 3-bit pair lookups without bank conflicts
-        extra.append("-DSQLLM_PAIR3_NOCONFLICT=" + str(int(os.environ["SQLLM_PAIR3_NOCONFLICT"])))
-    if os.environ.get("SQLLM_PIPE"):  # measurement builds: software-pipelined 4-bit chunk decode
-        extra.append("-DSQLLM_PIPE=" + str(int(os.environ["SQLLM_PIPE"])))
-    if os.environ.get("SQLLM_SCHED_PATTERN"):  # measurement builds: fixed decode-stage schedules
-        extra.append("-DSQLLM_SCHED_PATTERN=" + str(int(os.environ["SQLLM_SCHED_PATTERN"])))
-    extra += os.environ.get("SQLLM_EXTRA_DEFINES", "").split()  # measurement builds: e.g. "-DSQLLM_MFMA_VAR=4"
+ABLATION_LIB_NAME = "libsqllm_hip_ablation.so"
+ABLATION_LIB_PATH = os.path.join(HERE, ABLATION_LIB_NAME)
+# measurement-only preprocessor switches (environment variable -> macro).  They select kernel variants that
+# are slower or deliberately WRONG (ablations); a build that sets any of them is an ablation build and can
+# only be written to libsqllm_hip_ablation.so, never to the product library.
+VARIANT_ENV = ("SQLLM_WAVES", "SQLLM_PAIR3", "SQLLM_HALF_STAGES", "SQLLM_PAIR3_NOCONFLICT", "SQLLM_MFMA_VAR", "SQLLM_MFMA_FAKE")
+
+
+def _compile(out: str, extra, verbose: bool) -> str:
     cmd = [hipcc(), f"--offload-arch={ARCH}", *FLAGS, *extra, "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH + ".tmp"]
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+        raise BuildError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
     if verbose and res.stderr.strip():
         print(res.stderr, file=sys.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip -> squeezellm_amd/libsqllm_hip.so (cross-compiles without a GPU).  The product
+    build takes NO variant switches: the measurement variants live in build_ablation()."""
+    if not force and not is_stale():
+        return LIB_PATH
+    return _compile(LIB_PATH, [], verbose)
+
+
+def build_ablation(verbose: bool = False, out: str | None = None) -> str:
+    """Measurement build (ablation kernels, timeline probes, calibration kernels, and whatever variant
+    switches the environment names) -> libsqllm_hip_ablation.so (or `out`, which must not be the product
+    library).  Load it with SQLLM_LIB=<path>."""
+    out = os.path.abspath(out or ABLATION_LIB_PATH)
+    if out == os.path.abspath(LIB_PATH):
+        raise ValueError("an ablation build must not overwrite the product library")
+    extra = ["-DSQLLM_ABLATION_BUILD"]
+    for name in VARIANT_ENV:
+        if os.environ.get(name):
+            extra.append(f"-D{name}={int(os.environ[name])}")
+    extra += os.environ.get("SQLLM_EXTRA_DEFINES", "").split()
+    return _compile(out, extra, verbose)
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
-    print(path)
+    _verbose = "--verbose" in sys.argv or "-v" in sys.argv
+    if "--ablation" in sys.argv or os.environ.get("SQLLM_ABLATION") == "1":
+        _out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
+        print(build_ablation(verbose=_verbose, out=_out))
+    else:
+        print(build(force="--force" in sys.argv, verbose=_verbose))

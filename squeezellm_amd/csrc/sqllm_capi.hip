@@ -28,7 +28,7 @@ struct Knobs {
   //   4-bit: 2..4 rows column-lane kernel, 5..8 batch tiles of the batch-1 kernel, 9+ matrix cores
   //   3-bit: 2..16 rows column-lane kernel (two passes from 9 rows), 17+ matrix cores
   std::atomic<int> mfma_min_batch{0};  // rows from which the matrix-core kernel takes over
-  std::atomic<int> cols_min_batch{2};  // the column-lane kernel serves cols_min_batch .. cols_max_batch rows
+  std::atomic<int> cols_min_batch{0};  // the column-lane kernel serves cols_min_batch .. cols_max_batch rows (0 = default: 2)
   std::atomic<int> cols_max_batch{0};
   std::atomic<int> scratch_in_capture{1};  // stream-ordered scratch also while the stream is capturing (graph memory nodes)
   std::atomic<int> sparse_transpose{1};  // wide batches: the CSR role reads a transposed copy of vec (stream-ordered scratch)
@@ -46,6 +46,28 @@ Knobs& knobs() {
   }
   if (dev < 0 || dev >= kMaxDevices) dev = 0;
   return g_knobs[dev];
+}
+
+// The wide-batch CSR path takes stream-ordered scratch (hipMallocAsync) per op.  The default pool's
+// release threshold is 0: every synchronisation hands the block back to the OS and the next call pays
+// a real allocation + map.  Raise it once per device (never lower it) so that the pool keeps what one
+// op needs (2048 rows x K = 22016 floats is 180 MB).
+void keep_scratch_in_pool() {
+  static std::atomic<unsigned> done{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) { (void)hipGetLastError(); return; }
+  const unsigned bit = 1u << dev;
+  if (done.load(std::memory_order_relaxed) & bit) return;
+  done.fetch_or(bit, std::memory_order_relaxed);
+  hipMemPool_t pool = nullptr;
+  if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess || !pool) { (void)hipGetLastError(); return; }
+  uint64_t cur = 0;
+  const uint64_t want = 256ull << 20;
+  if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &cur) != hipSuccess) { (void)hipGetLastError(); cur = 0; }
+  if (cur < want) {
+    uint64_t v = want;
+    if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &v) != hipSuccess) (void)hipGetLastError();
+  }
 }
 
 int cu_count() {
@@ -209,9 +231,13 @@ void make_plan_cols(const sqllm_op* op, sqllm::KernelGeom* gm) {
   gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
 }
 
+int cols_min_batch_of() {
+  const int v = knobs().cols_min_batch.load(std::memory_order_relaxed);
+  return v > 0 ? v : 2;
+}
+
 bool takes_cols_path(const sqllm_op* op) {
-  return !takes_mfma_path(op) && op->batch >= 1 && op->batch >= knobs().cols_min_batch.load(std::memory_order_relaxed) &&
-         op->batch <= cols_max_batch_of(op);
+  return !takes_mfma_path(op) && op->batch >= 1 && op->batch >= cols_min_batch_of() && op->batch <= cols_max_batch_of(op);
 }
 
 }  // namespace
@@ -249,7 +275,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "sparse_last")) { knobs().sparse_last.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { knobs().cu_count.store(value); return SQLLM_OK; }  // for GPU-less planning tests
   if (!strcmp(name, "mfma_min_batch")) { knobs().mfma_min_batch.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "cols_min_batch")) { knobs().cols_min_batch.store(value < 1 ? 1 : value); return SQLLM_OK; }
+  if (!strcmp(name, "cols_min_batch")) { knobs().cols_min_batch.store(value); return SQLLM_OK; }
   if (!strcmp(name, "cols_max_batch")) { knobs().cols_max_batch.store(value); return SQLLM_OK; }
   if (!strcmp(name, "sparse_transpose")) { knobs().sparse_transpose.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "scratch_in_capture")) { knobs().scratch_in_capture.store(value ? 1 : 0); return SQLLM_OK; }
@@ -338,6 +364,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       }
       if (scratch_ok) {
         Bp = (ops[0].batch + 63) / 64 * 64;
+        keep_scratch_in_pool();
         void* p = nullptr;
         if (hipMallocAsync(&p, (size_t)ops[0].K * Bp * sizeof(float), static_cast<hipStream_t>(stream)) == hipSuccess && p) {
           xT = static_cast<float*>(p);

@@ -3,6 +3,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Measurement switches.  Every one of them selects a kernel variant that is slower or deliberately
+// WRONG (an ablation); they exist only in measurement builds (python -m squeezellm_amd.build
+// --ablation -> libsqllm_hip_ablation.so, never the product library).  A product build that sets
+// one of them does not compile.
+#ifndef SQLLM_ABLATION_BUILD
+#if defined(SQLLM_PAIR3) || defined(SQLLM_PAIR3_NOCONFLICT) || defined(SQLLM_MFMA_VAR) || defined(SQLLM_MFMA_FAKE) || \
+    defined(SQLLM_HALF_STAGES) || defined(SQLLM_WAVES)
+#error "kernel variant switches need -DSQLLM_ABLATION_BUILD (python -m squeezellm_amd.build --ablation)"
+#endif
+#endif
 #ifndef SQLLM_WAVES
 #define SQLLM_WAVES 8  // waves per workgroup (measurement builds: 4)
 #endif

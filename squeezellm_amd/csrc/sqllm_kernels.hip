@@ -51,12 +51,7 @@
 
 #include "sqllm_kernels.h"
 
-#ifndef SQLLM_SCHED_PATTERN
-#define SQLLM_SCHED_PATTERN 0
-#endif
-#ifndef SQLLM_PIPE
-#define SQLLM_PIPE 0
-#endif
+// measurement switches (guarded in sqllm_kernels.h: measurement builds only); production values:
 #ifndef SQLLM_PAIR3
 #define SQLLM_PAIR3 1  // 0 (measurement builds): 3-bit batch-1 decode with one lookup per weight
 #endif
@@ -242,107 +237,7 @@ __device__ __forceinline__ void step4(const u32x4& slot, const float (&xslot)[BT
     v[j][7] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0700u) + off);
   }
   fma_stage<BT, XL, ABL>(v, xv, acc);
-#if SQLLM_SCHED_PATTERN == 1
-  // fixed stage schedule: per column 3 split ops, then address / lookup pairs; the FMAs follow
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-  }
-#elif SQLLM_SCHED_PATTERN == 2
-  // all addresses of a column, then its 8 lookups
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-  }
-#elif SQLLM_SCHED_PATTERN == 3
-  // every address first, then the 32 lookups back to back
-  __builtin_amdgcn_sched_group_barrier(0x002, 44, 0);
-  __builtin_amdgcn_sched_group_barrier(0x100, 32, 0);
-#endif
   __builtin_amdgcn_sched_barrier(0);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Software-pipelined 4-bit chunk decode (SQLLM_PIPE): the lookups of step s+1 are issued in the same
-// scheduling region as the FMAs of step s, so their LDS latency is covered by the wave's own FMAs
-// instead of by other waves (costs a second set of 32 lookup registers).  Steps past the slice's end
-// are not skipped but multiplied by zero (their weights are clamped re-reads): no branches.
-// ------------------------------------------------------------------------------------------------
-template <int ABL>
-__device__ __forceinline__ void lookup4(const u32x4& slot, uint32_t lane_off, f32x2 (&vp)[2][8]) {
-  uint32_t t[4] = {slot.x, slot.y, slot.z, slot.w};
-  SQLLM_PIN4(t[0], t[1], t[2], t[3]);
-  // vp[p][i] = the values of weights k = i of columns 2p (.x) and 2p+1 (.y): the operand pairs of
-  // the packed FMAs, built in place so that no array of scalars has to be re-paired
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint32_t lo = t[j] & 0x0F0F0F0Fu;
-    const uint32_t hi = (t[j] >> 4) & 0x0F0F0F0Fu;
-    const int off = (j >> 1) * 4096 + (j & 1) * 128;
-    float e[8];
-    e[0] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0400u) + off);
-    e[1] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0400u) + off);
-    e[2] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0500u) + off);
-    e[3] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0500u) + off);
-    e[4] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0600u) + off);
-    e[5] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0600u) + off);
-    e[6] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0700u) + off);
-    e[7] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0700u) + off);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (j & 1) vp[j >> 1][i].y = e[i]; else vp[j >> 1][i].x = e[i];
-    }
-  }
-}
-
-template <int BT, int XL, int ABL>
-__device__ __forceinline__ void fma4(const f32x2 (&vp)[2][8], const float (&xslot)[BT], bool valid, f32x2 (&acc)[2][BT]) {
-#pragma unroll
-  for (int b = 0; b < BT; ++b) {
-    const float xv = valid ? xslot[b] : 0.f;
-    const float x0 = row_bcast<XL + 0>(xv), x1 = row_bcast<XL + 1>(xv), x2 = row_bcast<XL + 2>(xv), x3 = row_bcast<XL + 3>(xv);
-    const float x4 = row_bcast<XL + 4>(xv), x5 = row_bcast<XL + 5>(xv), x6 = row_bcast<XL + 6>(xv), x7 = row_bcast<XL + 7>(xv);
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-      f32x2 a = acc[jp][b];
-      a = __builtin_elementwise_fma(vp[jp][0], f32x2{x0, x0}, a);
-      a = __builtin_elementwise_fma(vp[jp][1], f32x2{x1, x1}, a);
-      a = __builtin_elementwise_fma(vp[jp][2], f32x2{x2, x2}, a);
-      a = __builtin_elementwise_fma(vp[jp][3], f32x2{x3, x3}, a);
-      a = __builtin_elementwise_fma(vp[jp][4], f32x2{x4, x4}, a);
-      a = __builtin_elementwise_fma(vp[jp][5], f32x2{x5, x5}, a);
-      a = __builtin_elementwise_fma(vp[jp][6], f32x2{x6, x6}, a);
-      a = __builtin_elementwise_fma(vp[jp][7], f32x2{x7, x7}, a);
-      acc[jp][b] = a;
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int BT, int NB, int ABL>
-__device__ __forceinline__ void decode4_pipelined(const u32x4 (&w)[NB][1], const float (&xs)[NB / 2][BT], int u,
-                                                  int grp, int u_end, int step, uint32_t lane_off,
-                                                  f32x2 (&acc)[2][BT]) {
-  static_assert(NB == 2 || NB == 4, "chunk of 2 or 4 steps");
-  f32x2 va[2][8], vb[2][8];
-  lookup4<ABL>(w[0][0], lane_off, va);
-  lookup4<ABL>(w[1][0], lane_off, vb);
-  fma4<BT, 0, ABL>(va, xs[0], u + grp < u_end, acc);
-  if constexpr (NB == 4) {
-    lookup4<ABL>(w[2][0], lane_off, va);
-    fma4<BT, 8, ABL>(vb, xs[0], u + step + grp < u_end, acc);
-    lookup4<ABL>(w[3][0], lane_off, vb);
-    fma4<BT, 0, ABL>(va, xs[1], u + 2 * step + grp < u_end, acc);
-    fma4<BT, 8, ABL>(vb, xs[1], u + 3 * step + grp < u_end, acc);
-  } else {
-    fma4<BT, 8, ABL>(vb, xs[0], u + step + grp < u_end, acc);
-  }
 }
 
 // packed FMAs of ONE column pair: vp[i] = the values of weight k = i of the pair's two columns
@@ -622,6 +517,20 @@ __device__ __forceinline__ void acc_add(float* p, float v) {
 __device__ __forceinline__ void acc_add(u64* p, float v) {
   __hip_atomic_fetch_add(SQLLM_GLOBAL(u64, p), to_fixed(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// Force every field of a segment descriptor into registers HERE (an empty asm statement that names the
+// value as a scalar INPUT operand: the loads feeding it must have completed; an in/out operand would
+// also hide where a pointer came from and turn every access through it into a FLAT instruction): the
+// compiler otherwise keeps a pointer per field and loads each one where it is first used, one
+// dependent scalar-load round trip (0.15 us) at a time.
+// (ONE statement for all of them: every asm statement waits for its own operands, and loads are not
+// moved above an earlier volatile asm.)
+#define SQLLM_SEG_OPERANDS(sg)                                                                                         \
+  "s"(sg.q), "s"(sg.y), "s"(sg.lut), "s"(sg.rows), "s"(sg.cols), "s"(sg.vals), "s"(sg.full_rows), "s"(sg.full_idx),    \
+  "s"(sg.bias), "s"(sg.out16), "s"(sg.gm.K), "s"(sg.gm.N), "s"(sg.gm.batch), "s"(sg.gm.col_tiles),                     \
+  "s"(sg.gm.units_total), "s"(sg.gm.units_per_wg), "s"(sg.gm.k_slices), "s"(sg.gm.dense_blocks),                       \
+  "s"(sg.gm.dense_block0), "s"(sg.gm.csr_blocks), "s"(sg.gm.topx_blocks), "s"(sg.gm.nnz), "s"(sg.gm.topX),             \
+  "s"(sg.gm.sparse_last)
 
 // ------------------------------------------------------------------------------------------------
 // Dense epilogue (shared by the dense-role variants): fold the 4 lane rows, then the waves through
@@ -951,9 +860,7 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   // u = this wave's (uniform) unit for the chunk's first step: guards are scalar branches; only the
   // per-row validity of a slice's ragged end is per lane (it zeroes x, no divergence)
   auto decode_chunk = [&](int u, const u32x4 (&w)[NBUF][R], const float (&xs)[NXR][BT]) {
-    if constexpr (BITS == 4 && SQLLM_PIPE && !(ABL & 2)) {
-      decode4_pipelined<BT, NBUF, ABL>(w, xs, u, grp, u_end, STEP, lane_off, acc);
-    } else if constexpr (BITS == 4) {
+    if constexpr (BITS == 4) {
 #pragma unroll
       for (int s2 = 0; s2 < NBUF / 2; ++s2) {
         const int ua = u + 2 * s2 * STEP, ub = ua + STEP;
@@ -1402,14 +1309,29 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
   using AT = typename AccType<LIN>::type;
   const XT* x = reinterpret_cast<const XT*>(xv);
 
+  // The argument block lives in memory and is read with scalar loads; a DEPENDENT scalar load costs
+  // 0.15-0.17 us here (tools/experiments/dispatch_ramp.hip: a chain of 8 takes 1.25 us, for the first
+  // workgroup of a CU and for the later ones alike).  Reading fields where they are used made the
+  // prologue a chain of 6-8 such loads (block0 -> s -> sparse_last -> dense_block0 -> dense_blocks ->
+  // ... -> q, lut) in front of the first vector load of every workgroup.  So: ONE round of loads
+  // fetches vec's address, the block table and -- speculatively -- the whole of segment 0 into
+  // registers; a workgroup of another segment pays a second round for its own descriptor.
+  Segment sg = ga.seg[0];
+  const int n_seg = ga.n_seg, blk1 = ga.block0[1], blk2 = ga.block0[2], blk3 = ga.block0[3];
+  asm volatile("" ::SQLLM_SEG_OPERANDS(sg), "s"(x), "s"(n_seg), "s"(blk1), "s"(blk2), "s"(blk3));
+  __builtin_amdgcn_sched_barrier(0);  // (or the scheduler starts on the block table after the first few loads, waits, and issues the rest behind that wait)
   // which op of the launch this workgroup belongs to (wave-uniform; 1 segment = a plain op)
-  int s = 0;
-#pragma unroll
-  for (int i = 1; i < kMaxSegments; ++i)
-    if (i < ga.n_seg && (int)blockIdx.x >= ga.block0[i]) s = i;
-  const Segment& sg = ga.seg[s];
+  int s = 0, base = 0;
+  if (n_seg > 1 && (int)blockIdx.x >= blk1) { s = 1; base = blk1; }
+  if (n_seg > 2 && (int)blockIdx.x >= blk2) { s = 2; base = blk2; }
+  if (n_seg > 3 && (int)blockIdx.x >= blk3) { s = 3; base = blk3; }
+  s = __builtin_amdgcn_readfirstlane(s);
+  if (s != 0) {
+    sg = ga.seg[s];
+    asm volatile("" ::SQLLM_SEG_OPERANDS(sg));
+  }
   const KernelGeom& gm = sg.gm;
-  const int bid = blockIdx.x - ga.block0[s];
+  const int bid = blockIdx.x - base;
   const int b0 = blockIdx.y * BT;
   int nb = gm.batch - b0;
   if (nb > BT) nb = BT;
@@ -1425,10 +1347,10 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
   }
   if (d >= 0 && d < gm.dense_blocks) {
     dense_role<BITS, BT, WAVES, ABL, XT, HALF>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, b0, nb,
-                                         d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds, sg, LIN ? &sg : nullptr);
+                                         d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds, sg, LIN ? &ga.seg[s] : nullptr);
   } else if (sp >= 0 && sp < gm.csr_blocks) {
     csr_role<T, BT, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds,
-                        LIN ? &sg : nullptr, gm.sparse_last >> 1);
+                        LIN ? &ga.seg[s] : nullptr, gm.sparse_last >> 1);
   } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
     // (never taken when the plan folds the top-X rows into the dense tiles)
     topx_role<T, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, b0, nb, sp - gm.csr_blocks, lds);
@@ -1762,7 +1684,9 @@ template <int BITS, int MB, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, (BITS == 4 && MB <= 2 && !(SQLLM_MFMA_VAR & 256)) ? 4 : 1)
 sqllm_fused_batched(const float* x, const GroupArgs ga) {
   __shared__ __attribute__((aligned(16))) float lds[mfma_lds_floats(BITS, MB, WAVES)];
-  const Segment& sg = ga.seg[0];
+  const Segment sg = ga.seg[0];  // the whole descriptor in one round of scalar loads (see sqllm_fused_matvec)
+  asm volatile("" ::SQLLM_SEG_OPERANDS(sg), "s"(x));
+  __builtin_amdgcn_sched_barrier(0);
   const KernelGeom& gm = sg.gm;
   const int m0 = blockIdx.y * 16 * MB;
   dense_role_mfma<BITS, MB, WAVES>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, gm.batch, m0,
@@ -1780,7 +1704,9 @@ __global__ void __launch_bounds__(WAVES * 64)
 sqllm_sparse_batched(const float* x, const GroupArgs ga, const float* xT, int Bp) {
   constexpr int T = WAVES * 64;
   __shared__ __attribute__((aligned(16))) float lds[cmax(kCsrSpanMax + cmax(kCsrSpanMax, 64 * (kCsrXtSpan + 1)), kTopxLds)];
-  const Segment& sg = ga.seg[0];
+  const Segment sg = ga.seg[0];  // the whole descriptor in one round of scalar loads (see sqllm_fused_matvec)
+  asm volatile("" ::SQLLM_SEG_OPERANDS(sg), "s"(x));
+  __builtin_amdgcn_sched_barrier(0);
   const KernelGeom& gm = sg.gm;
   const int sp = blockIdx.x;
   const int m0 = blockIdx.y * 64;
@@ -2060,7 +1986,9 @@ __global__ void __launch_bounds__(WAVES * 64)
 sqllm_fused_cols(const float* x, const GroupArgs ga) {
   constexpr int T = WAVES * 64;
   __shared__ __attribute__((aligned(16))) float lds[cols_lds_floats(BITS, BT, WAVES)];
-  const Segment& sg = ga.seg[0];
+  const Segment sg = ga.seg[0];  // the whole descriptor in one round of scalar loads (see sqllm_fused_matvec)
+  asm volatile("" ::SQLLM_SEG_OPERANDS(sg), "s"(x));
+  __builtin_amdgcn_sched_barrier(0);
   const KernelGeom& gm = sg.gm;
   const int bid = blockIdx.x;
   const int b0 = blockIdx.y * BT;
@@ -2288,13 +2216,19 @@ hipError_t check_csr(const int* rows, int N, int nnz, hipStream_t stream, int* b
   *bad = 0;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return hipSuccess;
-  static int* flag = nullptr;  // 4 bytes of device memory, allocated on first use of the debug option
+  // The 4-byte flag is stream-ordered scratch of the CURRENT device (the option is per device and
+  // several GPUs can be driven from one process: a process-wide buffer would live on whichever device
+  // used the option first).  Debug path: the allocation cost does not matter.
+  int* flag = nullptr;
   hipError_t e;
-  if (!flag && (e = hipMalloc(&flag, sizeof(int))) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(flag, 0, sizeof(int), stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(sqllm_check_csr, dim3((N + 255) / 256), dim3(256), 0, stream, rows, N, nnz, flag);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(bad, flag, sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  if ((e = hipMallocAsync(reinterpret_cast<void**>(&flag), sizeof(int), stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(flag, 0, sizeof(int), stream)) == hipSuccess) {
+    hipLaunchKernelGGL(sqllm_check_csr, dim3((N + 255) / 256), dim3(256), 0, stream, rows, N, nnz, flag);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(bad, flag, sizeof(int), hipMemcpyDeviceToHost, stream);
+  (void)hipFreeAsync(flag, stream);
+  if (e != hipSuccess) return e;
   return hipStreamSynchronize(stream);
 }
 

@@ -23,9 +23,14 @@ def pytest_configure(config):
 
     try:
         sq_build.build()
-    except RuntimeError as e:  # hipcc missing or failing
+    except sq_build.HipccMissing as e:
+        # No ROCm toolchain on this host.  A library that is already there AND newer than its sources
+        # (e.g. it travelled with the tree) is used; anything else skips the tests that need it.
         if not os.path.exists(sq_build.LIB_PATH):
             _lib_problem = str(e).splitlines()[0]
+        elif sq_build.is_stale():
+            _lib_problem = "libsqllm_hip.so is older than its sources and hipcc is not here to rebuild it"
+    # (a BuildError -- hipcc ran and the sources do not compile -- propagates: never test a stale binary)
     if not os.path.exists(os.path.join(ROOT, "oracle", "libsqllm_oracle.so")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "libsqllm_oracle.so"], check=True,
                        capture_output=True)

@@ -75,14 +75,14 @@ def test_plan_geometry():
     assert (p3["grid_x"] - p3["dense_blocks"]) % 8 == 0  # dense ids stay XCD-aligned
     assert _lib.plan_query(4, 4096, 4096, batch=3)["grid_y"] == 1
     # 2 .. 4 rows take the column-lane kernel: equal ranges of the flattened (tile, unit) space, ~3 per CU
-    assert _lib.get_option("cols_min_batch") == 2 and _lib.get_option("cols_max_batch") == 0  # 0 = default: 4 (4-bit), 16 (3-bit)
+    assert _lib.get_option("cols_min_batch") == 0 and _lib.get_option("cols_max_batch") == 0  # 0 = defaults: 2 .. 4 (4-bit), 2 .. 16 (3-bit)
     pc = _lib.plan_query(4, 5120, 13824, batch=4)
     total = pc["col_tiles"] * (5120 // 8)
     assert pc["grid_y"] == 1 and pc["groups_per_wave"] % 8 == 0 and 700 <= pc["dense_blocks"] <= 768
     assert pc["dense_blocks"] * pc["groups_per_wave"] >= total > (pc["dense_blocks"] - 1) * pc["groups_per_wave"]
     _lib.set_option("cols_min_batch", 1 << 30)  # switched off: the batch tiles of the batch-1 kernel
     assert _lib.plan_query(4, 5120, 13824, batch=4)["dense_blocks"] == pc["col_tiles"] * _lib.plan_query(4, 5120, 13824, batch=4)["k_slices"]
-    _lib.set_option("cols_min_batch", 2)
+    _lib.set_option("cols_min_batch", 0)
     # batches from `mfma_min_batch` (9) rows up take the matrix-core kernel: passes of 16 / 32 / 64 rows
     assert _lib.get_option("mfma_min_batch") == 0  # = the measured default: 9 rows (4-bit), 17 (3-bit)
     assert _lib.plan_query(4, 4096, 4096, batch=8)["grid_y"] == 1 and _lib.plan_query(3, 4096, 4096, batch=16)["grid_y"] == 2
@@ -259,7 +259,7 @@ def test_every_documented_option_round_trips():
     names = sorted(set(re.findall(r'"([a-z_]+)"', block)))
     assert {"target_wgs", "groups_per_wave", "sparse_last", "cu_count", "mfma_min_batch", "cols_min_batch", "cols_max_batch",
             "sparse_transpose", "scratch_in_capture", "validate_csr"} <= set(names)
-    defaults = {"mfma_min_batch": 0, "cols_min_batch": 2, "cols_max_batch": 0, "sparse_transpose": 1, "scratch_in_capture": 1,
+    defaults = {"mfma_min_batch": 0, "cols_min_batch": 0, "cols_max_batch": 0, "sparse_transpose": 1, "scratch_in_capture": 1,
                 "validate_csr": 0, "sparse_last": 0, "target_wgs": 0, "groups_per_wave": 0}
     for n in names:
         before = _lib.get_option(n)
