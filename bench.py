@@ -220,9 +220,10 @@ def time_blocks(step, sync, steps, warmup, repeats):
 # ---------------------------------------------------------------------------------------------------
 # CPU baselines (rank 0 of a 1-GPU run only, bounded samples)
 # ---------------------------------------------------------------------------------------------------
-def cpu_baseline_c_port(layers, model_layers: int, budget_s: float = 8.0):
+def cpu_baseline_c_port(layers, model_layers: int, xs=None, budget_s: float = 8.0):
     """The C port (oracle/libsqllm_oracle.so, OpenMP over the host cores) on decoder layers of the same
-    workload until ~budget_s of CPU time is spent; scaled to a whole pass."""
+    workload until ~budget_s of CPU time is spent; scaled to a whole pass.  With `xs` (the GPU pass's own
+    input tensors) the fp64 results are returned too: bench.py's parity spot compares the GPU pass with them."""
     import numpy as np
 
     lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libsqllm_oracle.so"))
@@ -235,14 +236,15 @@ def cpu_baseline_c_port(layers, model_layers: int, budget_s: float = 8.0):
     def P(a, t):
         return None if a is None else a.ctypes.data_as(t)
 
-    spent, done_layers, t_layers = 0.0, 0, []
+    spent, done_layers, t_layers, outs = 0.0, 0, [], []
     rng = np.random.default_rng(0)
     while spent < budget_s and done_layers < model_layers and done_layers < 4:
         ops = []
-        for lay in layers[done_layers * per_layer:(done_layers + 1) * per_layer]:
+        for i in range(done_layers * per_layer, (done_layers + 1) * per_layer):
+            lay = layers[i]
             h = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in lay.items()}
-            x = rng.normal(size=h["K"]).astype(np.float32)
-            ops.append((h, x, np.zeros(h["N"], np.float32), np.zeros(h["N"], np.float64)))
+            x = xs[i].cpu().numpy().astype(np.float32) if xs is not None else rng.normal(size=h["K"]).astype(np.float32)
+            ops.append((h, np.ascontiguousarray(x), np.zeros(h["N"], np.float32), np.zeros(h["N"], np.float64)))
         t0 = time.perf_counter()
         for h, x, mul, out in ops:
             topX = 0 if h["full_rows"] is None else h["full_rows"].shape[1]
@@ -255,9 +257,29 @@ def cpu_baseline_c_port(layers, model_layers: int, budget_s: float = 8.0):
         t_layers.append(dt)
         spent += dt
         done_layers += 1
+        outs.extend(o[3] for o in ops)
     best = min(t_layers)  # the first layer pays page faults / thread start-up
-    return dict(value=round(1.0 / (best * model_layers), 3), unit="tokens/s", threads=threads,
-                sample=f"{done_layers} of {model_layers} decoder layers, best layer {best * 1e3:.1f} ms, scaled x{model_layers}")
+    rec = dict(value=round(1.0 / (best * model_layers), 3), unit="tokens/s", threads=threads,
+               sample=f"{done_layers} of {model_layers} decoder layers, best layer {best * 1e3:.1f} ms, scaled x{model_layers}")
+    return rec, outs
+
+
+def parity_spot(seq, ys, ref_outs):
+    """One pass of the very launch sequence that was timed, from zeroed outputs, against the C port's fp64
+    results for the first len(ref_outs) ops (same weights, same inputs): max-norm relative error per op."""
+    import numpy as np
+    import torch
+
+    for y in ys:
+        y.zero_()
+    seq.launch()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for y, ref in zip(ys, ref_outs):
+        got = y.cpu().numpy().astype(np.float64)
+        worst = max(worst, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)))
+    return {"ops_checked": len(ref_outs), "max_rel_err": float(f"{worst:.3e}"), "tolerance": 2e-5, "ok": bool(worst <= 2e-5),
+            "against": "C port of the reference kernels (oracle/sqllm_oracle.c), fp64 accumulation, same weights and inputs"}
 
 
 def cpu_baseline_torch(layers, model_layers: int, budget_s: float = 6.0):
@@ -274,7 +296,7 @@ def cpu_baseline_torch(layers, model_layers: int, budget_s: float = 6.0):
     per_layer = len(layers) // model_layers
     g = torch.Generator().manual_seed(0)
     t_deq, t_mm, done, spent = [], [], 0, 0.0
-    while spent < budget_s and done < min(model_layers, 3):
+    while (spent < budget_s or done < 2) and done < min(model_layers, 4):
         ops = []
         for lay in layers[done * per_layer:(done + 1) * per_layer]:
             ops.append((lay["qweight"].cpu(), lay["lookup_table"].cpu(), lay["bits"], torch.randn(lay["K"], generator=g)))
@@ -282,7 +304,10 @@ def cpu_baseline_torch(layers, model_layers: int, budget_s: float = 6.0):
         Ws = []
         for q, lut, bits, x in ops:
             idx = pack.unpack_qweight(q, bits).to(torch.int64)   # [K, N]
-            W = lut.gather(1, idx.t().contiguous())              # [N, K]
+            # W[n, k] = lut[n, idx[k, n]]: flat take over the [N * 2^bits] table (a gather along dim 1 of an
+            # int64 [N, K] index walks it one element at a time: 7 s per decoder layer)
+            flat = (idx + torch.arange(idx.shape[1]).unsqueeze(0) * lut.shape[1]).t().contiguous()
+            W = lut.reshape(-1)[flat]                            # [N, K]
             Ws.append(W)
             _ = W @ x
         t1 = time.perf_counter()
@@ -303,6 +328,146 @@ def cpu_baseline_torch(layers, model_layers: int, budget_s: float = 6.0):
                                      ms_per_decoder_layer=round(min(t_mm) * 1e3, 2)),
                 sample=f"{done} of {model_layers} decoder layers ({per_layer} linears each) of the same workload, dense term, "
                        f"best layer scaled x{model_layers}")
+
+
+def cpu_leg_config1(budget_s: float = 10.0):
+    """BASELINE.json configs[0]: OPT-1.3B w4 dense-only, batch 1 x seq 128, the CPU torch dequant + matmul
+    reference path (squeezellm/quant.py:313-383 is the batched branch such an input takes; the reference
+    has no CPU kernel, so its "CPU path" is the dequantise-then-matmul restated in oracle/sqllm_oracle.py).
+    One decoder layer of the model's shapes (models/opt-1.3b/config.json:13-14,20: 2048 -> 2048 x4,
+    2048 -> 8192, 8192 -> 2048, with bias), x fp16 [128, 2048] -> fp32, all host cores; plus the C port."""
+    import numpy as np
+    import torch
+
+    from squeezellm_amd import pack, synth
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    spec = synth.MODEL_SHAPES["opt-1.3b"]
+    B = 128
+    layers = [synth.make_layer(K, N, 4, bias=True, device="cpu", seed=900 + j) for j, (_, K, N) in enumerate(spec["linears"])]
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(B, l["K"], generator=g, dtype=torch.float16).float() for l in layers]
+    t_deq, t_mm = [], []
+    Ws = None
+    t_start = time.perf_counter()
+    for _ in range(4):
+        t0 = time.perf_counter()
+        Ws = []
+        for l, x in zip(layers, xs):
+            idx = pack.unpack_qweight(l["qweight"], 4).to(torch.int64)
+            flat = (idx + torch.arange(l["N"]).unsqueeze(0) * 16).t().contiguous()
+            W = l["lookup_table"].reshape(-1)[flat]
+            Ws.append(W)
+            _ = (x @ W.t()).to(torch.float16) + l["bias"]
+        t1 = time.perf_counter()
+        for W, l, x in zip(Ws, layers, xs):
+            _ = (x @ W.t()).to(torch.float16) + l["bias"]
+        t2 = time.perf_counter()
+        t_deq.append(t1 - t0)
+        t_mm.append(t2 - t1)
+        if time.perf_counter() - t_start > budget_s:
+            break
+    # the C port over the same layer (batched entry point, OpenMP)
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libsqllm_oracle.so"))
+    lib.sqo_matvec.restype = ctypes.c_int
+    lib.sqo_num_threads.restype = ctypes.c_int
+    fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)
+    t_c = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        for l, x in zip(layers, xs):
+            xn = np.ascontiguousarray(x.numpy())
+            mul = np.zeros((B, l["N"]), np.float32)
+            out = np.zeros((B, l["N"]), np.float64)
+            q, lut = l["qweight"].numpy(), l["lookup_table"].numpy()
+            rc = lib.sqo_matvec(4, B, xn.ctypes.data_as(fp), q.ctypes.data_as(ip), mul.ctypes.data_as(fp), lut.ctypes.data_as(fp),
+                                l["K"], l["N"], None, None, None, None, None, 0, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+            assert rc == 0
+        t_c.append(time.perf_counter() - t0)
+    n_layers = spec["layers"]
+    tok = lambda t: round(B / (t * n_layers), 2)  # noqa: E731  tokens/s of a 128-token pass over the whole model
+    return {"workload": "opt-1.3b w4 s0 (dense-only), batch 1 x seq 128 (128 rows), CPU path; 1 of 24 decoder layers (6 linears, bias) timed, scaled x24",
+            "cores": cores, "torch_threads": torch.get_num_threads(),
+            "torch_dequant_matmul_f32": {"ms_per_decoder_layer": round(min(t_deq) * 1e3, 2), "tokens_per_s": tok(min(t_deq))},
+            "torch_matmul_only_f32": {"ms_per_decoder_layer": round(min(t_mm) * 1e3, 2), "tokens_per_s": tok(min(t_mm))},
+            "c_port_openmp": {"ms_per_decoder_layer": round(min(t_c) * 1e3, 2), "tokens_per_s": tok(min(t_c)), "threads": lib.sqo_num_threads()}}
+
+
+def drop_in_legs(layers, xs, dev, args, sync, model_layers, per_layer):
+    """What a caller gets WITHOUT the grouped-launch extension (squeezellm/llama.py:226-246
+    times the forward): the same 7B pass (a) as one operator launch per linear, graph-replayed, and (b)
+    through QuantLinearLUT.forward -- zeros / x.float() / operator / cast, four launches per linear
+    (squeezellm/quant.py:214-223,311-312; the mirror in squeezellm_amd/quant.py issues the same four) --
+    eager and graph-replayed, and (c) through the one-kernel fused linear, graph-replayed.  (b) and (c)
+    on the first 8 decoder layers, scaled to the model."""
+    import torch
+
+    from squeezellm_amd import decode, quant
+
+    rec = {}
+    ys = [torch.zeros(l["N"], device=dev) for l in layers]
+    seq = decode.OpSequence(layers, xs, ys, fuse_shared_input=False)
+    g = seq.graph(warmup=1)
+    blocks = time_blocks(g.replay, sync, 20, 3, 3)
+    ms = statistics.median(blocks) / 20 * 1e3
+    rec["op_per_linear_graph"] = {"launches_per_token": seq.n_groups, "ms_per_token": round(ms, 4), "tokens_per_s": round(1e3 / ms, 1)}
+    del seq, g, ys
+    n_dec = min(8, model_layers)
+    sub = layers[:n_dec * per_layer]
+    scale = model_layers / n_dec
+    x16 = {}
+    xs16 = []
+    for x in xs[:len(sub)]:
+        if id(x) not in x16:
+            x16[id(x)] = x.half().reshape(1, 1, -1)
+        xs16.append(x16[id(x)])
+    mods = [quant.QuantLinearLUT.from_operands(l) for l in sub]
+
+    def run(ms_):
+        with torch.no_grad():
+            for m, x in zip(ms_, xs16):
+                m(x)
+
+    def timed(fn, reps):
+        for _ in range(2):
+            fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        sync()
+        return (time.perf_counter() - t0) / reps * 1e3 * scale
+
+    def capture(fn):
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            fn()
+        return gr
+
+    t = timed(lambda: run(mods), 5)
+    rec["forward_eager"] = {"launches_per_linear": 4, "ms_per_token": round(t, 4), "tokens_per_s": round(1e3 / t, 1)}
+    gr = capture(lambda: run(mods))
+    t = timed(gr.replay, 20)
+    rec["forward_graph"] = {"launches_per_linear": 4, "ms_per_token": round(t, 4), "tokens_per_s": round(1e3 / t, 1)}
+    del gr
+    for m in mods:
+        m.__class__ = quant.QuantLinearLUTFused
+    run(mods)  # (first call: CSR check, workspace)
+    gr = capture(lambda: run(mods))
+    t = timed(gr.replay, 20)
+    rec["fused_linear_graph"] = {"launches_per_linear": 1, "ms_per_token": round(t, 4), "tokens_per_s": round(1e3 / t, 1)}
+    rec["note"] = (f"forward_* and fused_linear_graph: {n_dec} of {model_layers} decoder layers timed, scaled; fp16 activations; "
+                   "the headline `value` needs the grouped-launch entry point (sqllm_launch_groups / OpSequence), "
+                   "which squeezellm/quant.py unchanged does not call")
+    del gr, mods
+    torch.cuda.empty_cache()
+    return rec
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -327,7 +492,7 @@ def measure_replica(config_name, dev, rank, args, steps, warmup, repeats, sync, 
     else:
         step = seq.launch
     blocks = time_blocks(step, sync, steps, warmup, repeats)
-    out = dict(cfg=cfg, model_layers=model_layers, per_layer=len(spec["linears"]), layers=layers, seq=seq,
+    out = dict(cfg=cfg, model_layers=model_layers, per_layer=len(spec["linears"]), layers=layers, seq=seq, xs=xs, ys=ys,
                bytes_per_op=bytes_per_op, blocks=blocks, roofline=None, per_layer_us=None)
     if want_roofline:
         out["roofline"], out["per_layer_us"] = roofline_leg(seq, layers, bytes_per_op, cfg, config_name, not args.no_fuse)
@@ -485,19 +650,27 @@ def main():
             result["per_layer_us"] = m["per_layer_us"]
             if args.per_shape:
                 print(json.dumps(m["per_layer_us"], indent=1), file=sys.stderr)
+        headline_default = args.config == "7b-w4-s0" and args.layers is None and not args.no_fuse and args.launch == "graph"
         if not args.no_cpu_baseline:
-            # value = the reference-style path BASELINE.json names (torch dequant + matmul on the host
-            # cores); the other CPU legs ride along
-            cp = cpu_baseline_c_port(layers, model_layers)  # first: torch's OpenMP pool would spin beside it
+            # value = the C port of the kernels' algorithm on the host cores (kind "port"); the reference-style
+            # torch paths BASELINE.json names (dequant + matmul, matmul alone) ride along in `paths`
+            cp, ref_outs = cpu_baseline_c_port(layers, model_layers, xs=m["xs"])  # first: torch's OpenMP pool would spin beside it
+            # the C port has just computed the first decoder layers of the very pass that was timed: check it
+            result["parity_spot"] = parity_spot(seq, m["ys"], ref_outs)
             tb = cpu_baseline_torch(layers, model_layers)
             result["cpu_baseline"] = {
-                "value": tb["dequant_matmul_f32"]["value"], "unit": "tokens/s", "cores": tb["cores"], "kind": "port",
-                "sample": "torch codebook gather + torch.matmul, fp32, " + tb["sample"],
-                "paths": {"torch_dequant_matmul_f32": tb["dequant_matmul_f32"], "torch_matmul_only_f32": tb["matmul_only_f32"],
-                          "c_port_openmp": cp},
+                "value": cp["value"], "unit": "tokens/s", "cores": cp["threads"], "kind": "port",
+                "sample": "C port of the kernels (oracle/sqllm_oracle.c, OpenMP), " + cp["sample"],
+                "host_cores": tb["cores"],
+                "paths": {"c_port_openmp": cp,
+                          "torch_dequant_matmul_f32": dict(tb["dequant_matmul_f32"], sample=tb["sample"], threads=tb["threads"]),
+                          "torch_matmul_only_f32": dict(tb["matmul_only_f32"], sample=tb["sample"], threads=tb["threads"])},
             }
+            if headline_default:
+                result["cpu_baseline"]["config1_opt1.3b_seq128"] = cpu_leg_config1()
+        if headline_default and not args.no_sub_records:
+            result["drop_in"] = drop_in_legs(layers, m["xs"], dev, args, sync, model_layers, per_layer)
         # release the headline model before the sub-records build theirs
-        headline_default = args.config == "7b-w4-s0" and args.layers is None and not args.no_fuse and args.launch == "graph"
         del m, seq, layers
         torch.cuda.empty_cache()
         if headline_default and not args.no_sub_records:

@@ -111,6 +111,12 @@ def load() -> ctypes.CDLL:
     if lib.sqllm_abi_version() != 1:
         raise RuntimeError(f"libsqllm_hip.so ABI {lib.sqllm_abi_version()} != 1 expected by this package")
     _lib = lib
+    # SQLLM_OPTIONS="name=value,..." (measurement aid): library options applied to the current device at load
+    for item in filter(None, os.environ.get("SQLLM_OPTIONS", "").split(",")):
+        name, _, value = item.partition("=")
+        rc = lib.sqllm_set_option(name.strip().encode(), int(value))
+        if rc != 0:
+            raise RuntimeError(f"SQLLM_OPTIONS: {item!r} rejected ({rc})")
     return lib
 
 

@@ -33,6 +33,7 @@ struct Knobs {
   std::atomic<int> scratch_in_capture{1};  // stream-ordered scratch also while the stream is capturing (graph memory nodes)
   std::atomic<int> sparse_transpose{1};  // wide batches: the CSR role reads a transposed copy of vec (stream-ordered scratch)
   std::atomic<int> validate_csr{0};    // debug: check rows[] on the device before every launch that carries a CSR term
+  std::atomic<int> stream{-1};         // batch-1 operator launches on the streaming kernel: -1 = default (off), 0 / 1
   std::atomic<void*> timeline{nullptr};  // measurement build: per-workgroup timestamp buffer
 };
 constexpr int kMaxDevices = 32;
@@ -236,6 +237,66 @@ int cols_min_batch_of() {
   return v > 0 ? v : 2;
 }
 
+// Streaming batch-1 kernel (sqllm_stream.hip): does this launch take it, and with what geometry?
+bool takes_stream_path(const sqllm_op* ops, int n) {
+  const int v = knobs().stream.load(std::memory_order_relaxed);
+  if (v == 0) return false;
+  if (v < 0) return false;  // default: off until it beats the fused kernel on the box it is measured on
+  for (int i = 0; i < n; ++i)
+    if (ops[i].batch > 1) return false;
+  return true;
+}
+
+// The dense work of the launch = the ops' 64-column tiles back to back, `steps_per_tile` steps each (a step
+// = 4 units = one wave load); equal contiguous ranges, one per workgroup, ONE resident round: as many
+// workgroups as the chip holds at once minus the launch's sparse-role workgroups (they come first in the
+// grid and hold slots of their own), at least two steps per wave where the launch is small.  A range
+// may touch at most `pieces` tiles (their codebooks are all staged up front).
+void make_plan_stream(const sqllm_op* ops, int n, int sparse_blocks, sqllm::StreamArgs* sa) {
+  const int bits = ops[0].bits;
+  const int kK = bits == 4 ? 8 : 32;
+  const int pieces = bits == 4 ? sqllm::kStreamPieces4 : sqllm::kStreamPieces3;
+  const int wg_per_cu = bits == 4 ? 3 : 2;
+  memset(sa, 0, sizeof(*sa));
+  sa->x = static_cast<const float*>(ops[0].vec);
+  sa->K = ops[0].K;
+  sa->units_total = ops[0].K / kK;
+  sa->steps_per_tile = (sa->units_total + 3) / 4;
+  sa->n_seg = n;
+  int tiles = 0;
+  for (int i = 0; i < sqllm::kMaxSegments; ++i) {
+    sqllm::StreamSeg& sg = sa->seg[i];
+    if (i < n) {
+      sg.q = reinterpret_cast<const uint32_t*>(ops[i].qweight);
+      sg.y = ops[i].mul;
+      sg.lut = ops[i].lookup_table;
+      sg.N = ops[i].N;
+      sg.tile0 = tiles;
+      tiles += (ops[i].N + sqllm::kTileN - 1) / sqllm::kTileN;
+    } else {
+      sg = sa->seg[0];
+      sg.tile0 = 0x7fffffff;
+    }
+  }
+  const long long total = (long long)tiles * sa->steps_per_tile;
+  sa->total_steps = (int)total;
+  int target = knobs().target_wgs.load(std::memory_order_relaxed);
+  if (target <= 0) {
+    const int slots = wg_per_cu * cu_count();
+    target = slots - sparse_blocks;
+    if (target < cu_count()) target = cu_count();
+    const long long by_work = total / (2 * sqllm::kWaves);  // >= 2 steps per wave
+    if (target > by_work) target = (int)(by_work < 1 ? 1 : by_work);
+  }
+  long long upw = (total + target - 1) / target;
+  if (upw < 1) upw = 1;
+  // at most `pieces` tiles per range: a range of upw steps touches <= ceil(upw / S) + 1 tiles
+  const long long upw_max = (long long)(pieces - 1) * sa->steps_per_tile;
+  if (upw > upw_max) upw = upw_max;
+  sa->steps_per_wg = (int)upw;
+  sa->n_dense = (int)((total + upw - 1) / upw);
+}
+
 bool takes_cols_path(const sqllm_op* op) {
   return !takes_mfma_path(op) && op->batch >= 1 && op->batch >= cols_min_batch_of() && op->batch <= cols_max_batch_of(op);
 }
@@ -280,6 +341,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "sparse_transpose")) { knobs().sparse_transpose.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "scratch_in_capture")) { knobs().scratch_in_capture.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { knobs().validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
+  if (!strcmp(name, "stream")) { knobs().stream.store(value > 1 ? -1 : value); return SQLLM_OK; }  // 0 off, 1 on, 2 default
 #ifdef SQLLM_ABLATION_BUILD
   if (!strcmp(name, "ablate")) { knobs().ablate.store(value); return SQLLM_OK; }
   if (!strcmp(name, "ablate_csr")) { knobs().ablate_csr.store(value); return SQLLM_OK; }
@@ -299,6 +361,7 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "sparse_transpose")) { *value = knobs().sparse_transpose.load(); return SQLLM_OK; }
   if (!strcmp(name, "scratch_in_capture")) { *value = knobs().scratch_in_capture.load(); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { *value = knobs().validate_csr.load(); return SQLLM_OK; }
+  if (!strcmp(name, "stream")) { const int v = knobs().stream.load(); *value = v < 0 ? 2 : v; return SQLLM_OK; }
   return SQLLM_E_OPTION;
 }
 
@@ -431,6 +494,43 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       if (rc != SQLLM_OK) return rc;
     }
     return SQLLM_OK;
+  }
+  if (!lin && takes_stream_path(ops, n)) {
+    // streaming kernel: [sparse-role workgroups of every op | pad to 8 | dense ranges]
+    sqllm::GroupArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.n_seg = n;
+    int block = 0;
+    for (int i = 0; i < n; ++i) {
+      const sqllm_op* op = &ops[i];
+      int rc = validate(op);
+      if (rc == SQLLM_OK) rc = validate_csr_values(op, stream);
+      if (rc != SQLLM_OK) return rc;
+      if (op->vec != ops[0].vec || op->K != ops[0].K || op->bits != ops[0].bits) return SQLLM_E_GROUP;
+      sqllm::Segment& sg = ga.seg[i];
+      sg.q = reinterpret_cast<const uint32_t*>(op->qweight);
+      sg.y = op->mul;
+      sg.lut = op->lookup_table;
+      sg.rows = op->rows;
+      sg.cols = op->cols;
+      sg.vals = op->vals;
+      sg.full_rows = op->topX > 0 ? op->full_rows : nullptr;
+      sg.full_idx = op->topX > 0 ? op->full_row_indices : nullptr;
+      make_plan(op, &sg.gm, n);
+      sg.gm.dense_blocks = 0;
+      sg.gm.dense_block0 = sg.gm.csr_blocks + sg.gm.topx_blocks;
+      ga.block0[i] = block;
+      block += sg.gm.csr_blocks + sg.gm.topx_blocks;
+    }
+    for (int i = n; i <= sqllm::kMaxSegments; ++i) ga.block0[i] = block;
+    sqllm::StreamArgs sa;
+    make_plan_stream(ops, n, block, &sa);
+    sa.dense_block0 = (block + 7) / 8 * 8;
+#ifdef SQLLM_ABLATION_BUILD
+    sa.probe = static_cast<unsigned long long*>(knobs().timeline.load(std::memory_order_relaxed));
+#endif
+    return static_cast<int>(sqllm::launch_stream(ops[0].bits, sa, ga, static_cast<hipStream_t>(stream), e0, e1,
+                                                 knobs().ablate.load(std::memory_order_relaxed)));
   }
   sqllm_op tmp[sqllm::kMaxSegments];
   if (lin) {

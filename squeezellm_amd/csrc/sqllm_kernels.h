@@ -98,6 +98,34 @@ struct LaunchArgs {
   int Bp = 0;
 };
 
+// ---- streaming batch-1 kernel (sqllm_stream.hip) ----
+constexpr int kStreamPieces4 = 3;  // 64-column tiles one workgroup's range may touch (codebook tables resident at once), 4-bit
+constexpr int kStreamPieces3 = 2;  // ... 3-bit (32 KiB pair tables)
+
+struct StreamSeg {  // one op of the launch, dense term only
+  const uint32_t* q;
+  float* y;
+  const float* lut;
+  int N;
+  int tile0;  // index of the op's first tile in the launch's flattened tile space (INT_MAX: unused slot)
+};
+
+// Dense part of a streaming launch: the ops' 64-column tiles back to back, each tile `steps_per_tile`
+// steps long (a step = 4 units = what one wave load covers), cut into ranges of `steps_per_wg` steps.
+struct StreamArgs {
+  const float* x;
+  int K;
+  int units_total;     // K / 8 (4-bit) or K / 32 (3-bit)
+  int steps_per_tile;  // ceil(units_total / 4)
+  int steps_per_wg;
+  int total_steps;     // tiles of all ops * steps_per_tile
+  int dense_block0;    // first dense workgroup id (the sparse-role workgroups come first)
+  int n_dense;         // dense workgroups
+  int n_seg;
+  StreamSeg seg[kMaxSegments];
+  unsigned long long* probe;  // measurement builds: 8 timestamps per workgroup (tools/timeline.py); null otherwise
+};
+
 // batch rows handled per weight pass for a given batch size (template instantiations 1/2/4/8)
 inline int batch_tile(int batch) { return batch <= 1 ? 1 : batch == 2 ? 2 : batch <= 4 ? 4 : 8; }
 
@@ -105,6 +133,9 @@ inline int batch_tile(int batch) { return batch <= 1 ? 1 : batch == 2 ? 2 : batc
 inline int mfma_row_blocks(int batch) { return batch <= 16 ? 1 : batch <= 32 ? 2 : 4; }
 
 hipError_t launch_fused(int bits, const LaunchArgs& a, hipStream_t stream);
+// `ga`: the sparse roles of the launch (block0[] = prefix over csr + top-X workgroups only)
+hipError_t launch_stream(int bits, const StreamArgs& sa, const GroupArgs& ga, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
+                         int ablate);
 hipError_t launch_batched_mfma(int bits, const LaunchArgs& a, hipStream_t stream);
 hipError_t launch_batched_cols(int bits, const LaunchArgs& a, hipStream_t stream);
 hipError_t transpose_vec(const float* x, float* xT, int batch, int K, int Bp, hipStream_t stream, hipEvent_t ev_start);

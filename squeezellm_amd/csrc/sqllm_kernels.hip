@@ -51,486 +51,10 @@
 
 #include "sqllm_kernels.h"
 
-// measurement switches (guarded in sqllm_kernels.h: measurement builds only); production values:
-#ifndef SQLLM_PAIR3
-#define SQLLM_PAIR3 1  // 0 (measurement builds): 3-bit batch-1 decode with one lookup per weight
-#endif
-#ifndef SQLLM_PAIR3_NOCONFLICT
-// 1 (measurement builds, WRONG RESULTS): the 3-bit pair lookups take their entry's parity from the
-// lane row instead of from the data, so the two lane rows of a half-wave can never meet on a bank --
-// same instruction count, zero bank conflicts: the A/B that prices the conflicts of the real layout
-#define SQLLM_PAIR3_NOCONFLICT 0
-#endif
-#ifndef SQLLM_MFMA_VAR
-#define SQLLM_MFMA_VAR 0
-#endif
-#ifndef SQLLM_MFMA_FAKE
-#define SQLLM_MFMA_FAKE 0  // 1 (measurement builds, wrong results): the wide-batch kernel without its matrix instructions
-#endif
-#ifndef SQLLM_HALF_STAGES
-#define SQLLM_HALF_STAGES 1  // 0 (measurement builds): whole-stage decode, 32 live lookups
-#endif
-
+#include "sqllm_decode.h"
+#include "sqllm_roles.h"
 
 namespace sqllm {
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// A "unit" is the smallest piece of K that can be decoded on its own: one qweight row (8 k's) for
-// 4-bit, three rows (32 k's, squeezellm/quant.py:185-203) for 3-bit.
-template <int BITS> struct Fmt;
-template <> struct Fmt<4> {
-  static constexpr int kLut = 16;   // codebook entries per channel
-  static constexpr int kRows = 1;   // qweight rows per unit
-  static constexpr int kK = 8;      // k's per unit
-};
-template <> struct Fmt<3> {
-  static constexpr int kLut = 8;
-  static constexpr int kRows = 3;
-  static constexpr int kK = 32;
-};
-// element type of vec: fp32 behind the reference operator names, fp16 for the fused linear
-template <bool LIN> struct XType { using type = float; };
-template <> struct XType<true> { using type = _Float16; };
-// accumulator word: the caller's fp32 `mul`, or the fused linear's fixed-point workspace plane
-template <bool LIN> struct AccType { using type = float; };
-template <> struct AccType<true> { using type = unsigned long long; };
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
-
-// broadcast lane P of each 16-lane DPP row to the whole row
-template <int P>
-__device__ __forceinline__ float row_bcast(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + P, 0xf, 0xf, true));
-}
-
-// ------------------------------------------------------------------------------------------------
-// Field extraction.  Both return the index already multiplied by 128 (bits [7, 7+BITS)), ready to be
-// OR-ed into an LDS byte address (one entry row of a sub-table is 32 slots x 4 B = 128 B).
-//
-// 3-bit: the three rows of a unit form one little-endian 96-bit stream in which weight k occupies
-// bits [3k, 3k+3): row0 bits 0-29 are k0..9, row0[30:31] + row1[0] are k10, row1[1:30] are k11..20,
-// row1[31] + row2[0:1] are k21, row2[2:31] are k22..31 -- exactly the layout pack2 writes
-// (squeezellm/quant.py:185-203) and the reference decodes with its two "straddler" expressions
-// (quant_cuda_kernel.cu:792, :809).
-// ------------------------------------------------------------------------------------------------
-template <int KIDX>
-__device__ __forceinline__ uint32_t field3_x128(uint32_t t0, uint32_t t1, uint32_t t2) {
-  constexpr int bit = 3 * KIDX;
-  constexpr int w = bit >> 5;
-  constexpr int o = bit & 31;
-  const uint32_t lo = (w == 0) ? t0 : (w == 1) ? t1 : t2;
-  uint32_t f;
-  if constexpr (o <= 29) {
-    if constexpr (o > 7) f = lo >> (o - 7);
-    else if constexpr (o < 7) f = lo << (7 - o);
-    else f = lo;
-  } else {
-    const uint32_t hi = (w == 0) ? t1 : t2;
-    f = __builtin_amdgcn_alignbit(hi, lo, o) << 7;
-  }
-  return f & 0x380u;
-}
-
-template <int P>
-__device__ __forceinline__ uint32_t field4_x128(uint32_t t) {
-  uint32_t f;
-  if constexpr (4 * P > 7) f = t >> (4 * P - 7);
-  else f = t << (7 - 4 * P);
-  return f & 0x780u;
-}
-
-__device__ __forceinline__ float lds_read_f32(uint32_t byte_addr) {
-  return *reinterpret_cast<const float __attribute__((address_space(3)))*>(byte_addr);
-}
-
-// ABL (ablation bits, measurement builds only; 0 in production):
-//   1 = no LDS lookup (value = address bits), 2 = pure stream (no decode, no FMA),
-//   4 = no codebook staging, 8 = no epilogue (reduction + atomics)
-template <int ABL>
-__device__ __forceinline__ float lookup(uint32_t a) {
-  if constexpr (ABL & 1) return __builtin_bit_cast(float, a);
-  else return lds_read_f32(a);
-}
-
-// Pin values: nothing that consumes them can be placed above this point, and the statement is
-// ordered against the other pins / scheduling fences.  Keeps each decode stage's shifts from being
-// hoisted to the top of the loop body by instruction selection (which then spills).
-#define SQLLM_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-
-// ------------------------------------------------------------------------------------------------
-// One decode stage = 8 consecutive k's of this lane's 4 columns: 32 lookups, then 32 FMAs against
-// the 8 broadcast x values; the scheduling fence closes the stage.
-//   4-bit: a stage is one qweight row (the lane's uint4).
-//   3-bit: a unit has 4 stages Q = 0..3 (k = 8Q .. 8Q+7) over the three uint4 of the unit.
-// XL = lane (within the 16-lane row) holding x of the stage's first k.
-// ------------------------------------------------------------------------------------------------
-template <int BT, int XL, int ABL>
-__device__ __forceinline__ void fma_stage(const float (&v)[4][8], const float (&xv)[BT], f32x2 (&acc)[2][BT]) {
-  // packed fp32 FMAs (v_pk_fma_f32: two columns per instruction, x splat through op_sel): the
-  // kernel is issue-bound and this halves its FMA instructions
-#pragma unroll
-  for (int b = 0; b < BT; ++b) {
-    const float x0 = row_bcast<XL + 0>(xv[b]), x1 = row_bcast<XL + 1>(xv[b]);
-    const float x2 = row_bcast<XL + 2>(xv[b]), x3 = row_bcast<XL + 3>(xv[b]);
-    const float x4 = row_bcast<XL + 4>(xv[b]), x5 = row_bcast<XL + 5>(xv[b]);
-    const float x6 = row_bcast<XL + 6>(xv[b]), x7 = row_bcast<XL + 7>(xv[b]);
-#define SQLLM_PKFMA(I, X) a = __builtin_elementwise_fma(f32x2{v[2 * jp][I], v[2 * jp + 1][I]}, f32x2{X, X}, a)
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-      f32x2 a = acc[jp][b];
-      SQLLM_PKFMA(0, x0); SQLLM_PKFMA(1, x1); SQLLM_PKFMA(2, x2); SQLLM_PKFMA(3, x3);
-      SQLLM_PKFMA(4, x4); SQLLM_PKFMA(5, x5); SQLLM_PKFMA(6, x6); SQLLM_PKFMA(7, x7);
-      acc[jp][b] = a;
-    }
-#undef SQLLM_PKFMA
-  }
-}
-
-// 4-bit step: one qweight row of this lane's 4 columns x 8 weights.
-// Address generation is the VALU hot spot (the kernel is VALU-bound: every wave64 VALU op costs 4
-// cycles of its SIMD), so it is done with ONE v_perm_b32 per weight: the word is first split into
-// nibble-bytes  lo = w & 0x0F0F0F0F (nibbles 0,2,4,6)  and  hi = (w >> 4) & 0x0F0F0F0F (1,3,5,7)
-// -- 3 ops per 8 weights -- and the 4-bit table uses a 256-byte entry stride, so the LDS byte
-// address of a lookup is simply  [byte1 = nibble, byte0 = 4 * lane] : a byte permute of (nibble
-// word, lane-offset word).  The sub-table of column j sits at a constant +4096 j, which folds into
-// the ds_read's immediate offset.  XL = lane of the 16-lane row holding x of the row's first k.
-template <int BT, int XL, int ABL>
-__device__ __forceinline__ void step4(const u32x4& slot, const float (&xslot)[BT], bool valid,
-                                      uint32_t lane_off, f32x2 (&acc)[2][BT]) {
-  uint32_t t[4] = {slot.x, slot.y, slot.z, slot.w};
-  float xv[BT];
-  SQLLM_PIN4(t[0], t[1], t[2], t[3]);
-#pragma unroll
-  for (int b = 0; b < BT; ++b) xv[b] = valid ? xslot[b] : 0.f;
-  if constexpr (ABL & 2) {
-#pragma unroll
-    for (int b = 0; b < BT; ++b) {
-      acc[0][b].x += __builtin_bit_cast(float, t[0] ^ t[1]) * xv[b];
-      acc[1][b].x += __builtin_bit_cast(float, t[2] ^ t[3]) * xv[b];
-    }
-    return;
-  }
-  float v[4][8];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint32_t lo = t[j] & 0x0F0F0F0Fu;
-    const uint32_t hi = (t[j] >> 4) & 0x0F0F0F0Fu;
-    // columns j and j^1 share 256-byte entry rows (even column in the low 128 bytes, odd in the
-    // high), the pair (j >> 1) selects the 4 KiB half: both fold into the ds_read immediate.
-    // selector bytes (LSB first): byte0 <- lane_off.byte0, byte1 <- nibble word byte k, bytes 2,3 <- 0
-    constexpr int kNoOff = 0;
-    const int off = (j >> 1) * 4096 + (j & 1) * 128 + kNoOff;
-    v[j][0] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0400u) + off);
-    v[j][1] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0400u) + off);
-    v[j][2] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0500u) + off);
-    v[j][3] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0500u) + off);
-    v[j][4] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0600u) + off);
-    v[j][5] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0600u) + off);
-    v[j][6] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0700u) + off);
-    v[j][7] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0700u) + off);
-  }
-  fma_stage<BT, XL, ABL>(v, xv, acc);
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-// packed FMAs of ONE column pair: vp[i] = the values of weight k = i of the pair's two columns
-template <int BT, int XL>
-__device__ __forceinline__ void fma_pair(const f32x2 (&vp)[8], const float (&xv)[BT], f32x2 (&acc)[BT]) {
-#pragma unroll
-  for (int b = 0; b < BT; ++b) {
-    const float x0 = row_bcast<XL + 0>(xv[b]), x1 = row_bcast<XL + 1>(xv[b]), x2 = row_bcast<XL + 2>(xv[b]), x3 = row_bcast<XL + 3>(xv[b]);
-    const float x4 = row_bcast<XL + 4>(xv[b]), x5 = row_bcast<XL + 5>(xv[b]), x6 = row_bcast<XL + 6>(xv[b]), x7 = row_bcast<XL + 7>(xv[b]);
-    f32x2 a = acc[b];
-    a = __builtin_elementwise_fma(vp[0], f32x2{x0, x0}, a);
-    a = __builtin_elementwise_fma(vp[1], f32x2{x1, x1}, a);
-    a = __builtin_elementwise_fma(vp[2], f32x2{x2, x2}, a);
-    a = __builtin_elementwise_fma(vp[3], f32x2{x3, x3}, a);
-    a = __builtin_elementwise_fma(vp[4], f32x2{x4, x4}, a);
-    a = __builtin_elementwise_fma(vp[5], f32x2{x5, x5}, a);
-    a = __builtin_elementwise_fma(vp[6], f32x2{x6, x6}, a);
-    a = __builtin_elementwise_fma(vp[7], f32x2{x7, x7}, a);
-    acc[b] = a;
-  }
-}
-
-// Half-stage variant of the 4-bit step: one column PAIR at a time -- 16 lookups, then
-// their 8 packed FMAs -- so that only 16 lookup registers are live and the kernel fits 64 VGPRs
-// (four 8-wave workgroups per CU).
-template <int BT, int XL, int ABL>
-__device__ __forceinline__ void step4_half(const u32x4& slot, const float (&xslot)[BT], bool valid,
-                                           uint32_t lane_off, f32x2 (&acc)[2][BT]) {
-  uint32_t t[4] = {slot.x, slot.y, slot.z, slot.w};
-  SQLLM_PIN4(t[0], t[1], t[2], t[3]);
-  float xv[BT];
-#pragma unroll
-  for (int b = 0; b < BT; ++b) xv[b] = valid ? xslot[b] : 0.f;
-#pragma unroll
-  for (int jp = 0; jp < 2; ++jp) {
-    f32x2 vp[8];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int j = 2 * jp + h;
-      const uint32_t lo = t[j] & 0x0F0F0F0Fu;
-      const uint32_t hi = (t[j] >> 4) & 0x0F0F0F0Fu;
-      const int off = jp * 4096 + h * 128;
-      float e[8];
-      e[0] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0400u) + off);
-      e[1] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0400u) + off);
-      e[2] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0500u) + off);
-      e[3] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0500u) + off);
-      e[4] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0600u) + off);
-      e[5] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0600u) + off);
-      e[6] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0700u) + off);
-      e[7] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0700u) + off);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (h) vp[i].y = e[i]; else vp[i].x = e[i];
-      }
-    }
-    fma_pair<BT, XL>(vp, xv, acc[jp]);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-template <int BT, int Q, int ABL, bool HALF = false>
-__device__ __forceinline__ void stage3(const uint32_t (&t0)[4], const uint32_t (&t1)[4], const uint32_t (&t2)[4],
-                                       const uint32_t (&tb)[4], const float (&xlo)[BT], const float (&xhi)[BT],
-                                       f32x2 (&acc)[2][BT]) {
-  if constexpr (HALF) {  // one column pair at a time: 16 live lookups (see step4_half)
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-      f32x2 vp[8];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int j = 2 * jp + h;
-        float e[8];
-        e[0] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 0>(t0[j], t1[j], t2[j]));
-        e[1] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 1>(t0[j], t1[j], t2[j]));
-        e[2] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 2>(t0[j], t1[j], t2[j]));
-        e[3] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 3>(t0[j], t1[j], t2[j]));
-        e[4] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 4>(t0[j], t1[j], t2[j]));
-        e[5] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 5>(t0[j], t1[j], t2[j]));
-        e[6] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 6>(t0[j], t1[j], t2[j]));
-        e[7] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 7>(t0[j], t1[j], t2[j]));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          if (h) vp[i].y = e[i]; else vp[i].x = e[i];
-        }
-      }
-      if constexpr (Q < 2) fma_pair<BT, 8 * Q>(vp, xlo, acc[jp]);
-      else fma_pair<BT, 8 * (Q - 2)>(vp, xhi, acc[jp]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    return;
-  }
-  float v[4][8];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    v[j][0] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 0>(t0[j], t1[j], t2[j]));
-    v[j][1] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 1>(t0[j], t1[j], t2[j]));
-    v[j][2] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 2>(t0[j], t1[j], t2[j]));
-    v[j][3] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 3>(t0[j], t1[j], t2[j]));
-    v[j][4] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 4>(t0[j], t1[j], t2[j]));
-    v[j][5] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 5>(t0[j], t1[j], t2[j]));
-    v[j][6] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 6>(t0[j], t1[j], t2[j]));
-    v[j][7] = lookup<ABL>(tb[j] | field3_x128<8 * Q + 7>(t0[j], t1[j], t2[j]));
-  }
-  if constexpr (Q < 2) fma_stage<BT, 8 * Q, ABL>(v, xlo, acc);
-  else fma_stage<BT, 8 * (Q - 2), ABL>(v, xhi, acc);
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int BT, int ABL, bool HALF = false>
-__device__ __forceinline__ void step3(const u32x4 (&slot)[3], const float (&xslot0)[BT], const float (&xslot1)[BT],
-                                      bool valid, const uint32_t (&tb)[4], f32x2 (&acc)[2][BT]) {
-  uint32_t t0[4] = {slot[0].x, slot[0].y, slot[0].z, slot[0].w};
-  uint32_t t1[4] = {slot[1].x, slot[1].y, slot[1].z, slot[1].w};
-  uint32_t t2[4] = {slot[2].x, slot[2].y, slot[2].z, slot[2].w};
-  float xlo[BT], xhi[BT];
-  SQLLM_PIN4(t0[0], t0[1], t0[2], t0[3]);
-  SQLLM_PIN4(t1[0], t1[1], t1[2], t1[3]);
-  SQLLM_PIN4(t2[0], t2[1], t2[2], t2[3]);
-#pragma unroll
-  for (int b = 0; b < BT; ++b) {
-    xlo[b] = valid ? xslot0[b] : 0.f;
-    xhi[b] = valid ? xslot1[b] : 0.f;
-  }
-  stage3<BT, 0, ABL, HALF>(t0, t1, t2, tb, xlo, xhi, acc);
-  stage3<BT, 1, ABL, HALF>(t0, t1, t2, tb, xlo, xhi, acc);
-  stage3<BT, 2, ABL, HALF>(t0, t1, t2, tb, xlo, xhi, acc);
-  stage3<BT, 3, ABL, HALF>(t0, t1, t2, tb, xlo, xhi, acc);
-}
-
-// ------------------------------------------------------------------------------------------------
-// 3-bit PAIR decode (SQLLM_PAIR3; batch tile 1): the kernel is bound by the SUM of its vector and
-// LDS instructions, and the plain 3-bit path spends 4.1 of them per weight.
-// Here a column's codebook is staged as a 64-entry table of PAIRS -- entry i0 + 8 * i1 holds
-// (lut[i0], lut[i1]) -- so that one ds_read_b64, addressed by the 6-bit field of two consecutive
-// weights (k, k+1), returns both values, and one packed FMA multiplies them by (x[k], x[k+1]):
-// 2 address ops + 1 lookup + 1 FMA + 1/2 broadcast per TWO weights.  The accumulator of a column
-// is a float2 (even k, odd k), summed at the end.  32 KB of tables per 64-column tile.
-// ------------------------------------------------------------------------------------------------
-template <int M>  // pair M of a unit: weights k = 2M, 2M+1 = bits [6M, 6M+6) of the 96-bit stream; result << 7
-__device__ __forceinline__ uint32_t field6_x128(uint32_t t0, uint32_t t1, uint32_t t2) {
-  constexpr int bit = 6 * M;
-  constexpr int w = bit >> 5;
-  constexpr int o = bit & 31;
-  const uint32_t lo = (w == 0) ? t0 : (w == 1) ? t1 : t2;
-  uint32_t f;
-  if constexpr (o <= 26) {
-    if constexpr (o > 7) f = lo >> (o - 7);
-    else if constexpr (o < 7) f = lo << (7 - o);
-    else f = lo;
-  } else {  // pairs 5 and 10 straddle a dword boundary
-    const uint32_t hi = (w == 0) ? t1 : t2;
-    f = __builtin_amdgcn_alignbit(hi, lo, o) << 7;
-  }
-#if SQLLM_PAIR3_NOCONFLICT
-  return f & 0x1F00u;  // measurement build: entry parity comes from the lane row (see tb[] in dense_role)
-#else
-  return f & 0x1F80u;
-#endif
-}
-
-__device__ __forceinline__ f32x2 lds_read_f32x2(uint32_t byte_addr) {
-  return *reinterpret_cast<const f32x2 __attribute__((address_space(3)))*>(byte_addr);
-}
-
-// 8 pairs (16 k's) of ONE column: 8 lookups live at a time
-template <int H>
-__device__ __forceinline__ void stage3_pair(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t tbj,
-                                            const float (&xb)[16], f32x2& acc) {
-  f32x2 v[8];
-  v[0] = lds_read_f32x2(tbj | field6_x128<8 * H + 0>(t0, t1, t2));
-  v[1] = lds_read_f32x2(tbj | field6_x128<8 * H + 1>(t0, t1, t2));
-  v[2] = lds_read_f32x2(tbj | field6_x128<8 * H + 2>(t0, t1, t2));
-  v[3] = lds_read_f32x2(tbj | field6_x128<8 * H + 3>(t0, t1, t2));
-  v[4] = lds_read_f32x2(tbj | field6_x128<8 * H + 4>(t0, t1, t2));
-  v[5] = lds_read_f32x2(tbj | field6_x128<8 * H + 5>(t0, t1, t2));
-  v[6] = lds_read_f32x2(tbj | field6_x128<8 * H + 6>(t0, t1, t2));
-  v[7] = lds_read_f32x2(tbj | field6_x128<8 * H + 7>(t0, t1, t2));
-  f32x2 a = acc;
-  a = __builtin_elementwise_fma(v[0], f32x2{xb[0], xb[1]}, a);
-  a = __builtin_elementwise_fma(v[1], f32x2{xb[2], xb[3]}, a);
-  a = __builtin_elementwise_fma(v[2], f32x2{xb[4], xb[5]}, a);
-  a = __builtin_elementwise_fma(v[3], f32x2{xb[6], xb[7]}, a);
-  a = __builtin_elementwise_fma(v[4], f32x2{xb[8], xb[9]}, a);
-  a = __builtin_elementwise_fma(v[5], f32x2{xb[10], xb[11]}, a);
-  a = __builtin_elementwise_fma(v[6], f32x2{xb[12], xb[13]}, a);
-  a = __builtin_elementwise_fma(v[7], f32x2{xb[14], xb[15]}, a);
-  acc = a;
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-__device__ __forceinline__ void step3_pair(const u32x4 (&slot)[3], float xslot0, float xslot1, bool valid,
-                                           const uint32_t (&tb)[4], f32x2 (&accp)[4]) {
-  uint32_t t0[4] = {slot[0].x, slot[0].y, slot[0].z, slot[0].w};
-  uint32_t t1[4] = {slot[1].x, slot[1].y, slot[1].z, slot[1].w};
-  uint32_t t2[4] = {slot[2].x, slot[2].y, slot[2].z, slot[2].w};
-  SQLLM_PIN4(t0[0], t0[1], t0[2], t0[3]);
-  SQLLM_PIN4(t1[0], t1[1], t1[2], t1[3]);
-  SQLLM_PIN4(t2[0], t2[1], t2[2], t2[3]);
-  const float xlo = valid ? xslot0 : 0.f, xhi = valid ? xslot1 : 0.f;
-#define SQLLM_XB16(X) {row_bcast<0>(X), row_bcast<1>(X), row_bcast<2>(X), row_bcast<3>(X), row_bcast<4>(X), row_bcast<5>(X), \
-                       row_bcast<6>(X), row_bcast<7>(X), row_bcast<8>(X), row_bcast<9>(X), row_bcast<10>(X), row_bcast<11>(X), \
-                       row_bcast<12>(X), row_bcast<13>(X), row_bcast<14>(X), row_bcast<15>(X)}
-  {
-    const float xb[16] = SQLLM_XB16(xlo);  // x of k = 0..15 of the unit, broadcast along the 16-lane row
-#pragma unroll
-    for (int j = 0; j < 4; ++j) stage3_pair<0>(t0[j], t1[j], t2[j], tb[j], xb, accp[j]);
-  }
-  {
-    const float xb[16] = SQLLM_XB16(xhi);  // k = 16..31
-#pragma unroll
-    for (int j = 0; j < 4; ++j) stage3_pair<1>(t0[j], t1[j], t2[j], tb[j], xb, accp[j]);
-  }
-#undef SQLLM_XB16
-}
-
-// ------------------------------------------------------------------------------------------------
-// Fused-linear completion (sqllm_linear_f16: fp16 in, fp16 out, bias, no launches around the op --
-// the reference wraps every op in a zeros/clone, an x.float() and a y.to(fp16) kernel,
-// squeezellm/quant.py:214-223,311-312).
-//
-// The roles accumulate into a plane of 64-bit words in the caller's workspace, all zero between
-// launches.  A word is  count * 2^55 + S  with S the column's sum in signed fixed point (2^-28
-// units): integer adds commute, so ONE returning atomic add both deposits a contribution and
-// tells the contributor how many have arrived.  How many a column will receive is known to every
-// contributor without communication:
-//     every dense K slice of the column's tile            -> k_slices
-//   + every CSR chunk that holds part of the column's row -> from rows[c], rows[c+1] alone
-// (the top-X rows are folded into the dense workgroups of the tiles that own their columns, see
-// dense_role).  Whoever deposits the last contribution owns the column: bias, fp16 store, word
-// back to zero.  The critical path of a workgroup grows by one atomic round trip; there are no
-// fences (an agent-scope release/acquire pair costs an L2 write-back and an L2 invalidate per
-// workgroup here: measured +4.5 us per launch) and no launch-wide counter (a last-arriver that
-// must then touch all N columns measured +4-11 us per launch).
-//
-// Contributions are clamped to +-2^17 (twice the largest finite fp16) so that the at most 511 of
-// them a column can receive stay inside the 55-bit field; sums beyond that are not finite in
-// fp16 anyway.  Rounding: 2^-28 absolute per contribution, far below one fp16 ulp of any normal
-// fp16 result.
-// ------------------------------------------------------------------------------------------------
-typedef unsigned long long u64;
-constexpr int kFixShift = 28;
-constexpr int kCountShift = 55;
-constexpr u64 kCountUnit = 1ull << kCountShift;
-
-__device__ __forceinline__ u64 to_fixed(float v) {
-  v = __builtin_fminf(__builtin_fmaxf(v, -131072.f), 131072.f);  // also maps NaN to a bound
-  return (u64)(long long)__builtin_rintf(v * (float)(1 << kFixShift));
-}
-
-// CSR chunks (kCsrChunk consecutive non-zeros each) holding part of a row that spans [r0, r1)
-__device__ __forceinline__ int csr_chunks_of_row(int r0, int r1) {
-  return r1 > r0 ? (r1 - 1) / kCsrChunk - r0 / kCsrChunk + 1 : 0;
-}
-
-// `total` = the word after this thread's own counted add.  Finishes the column if that add was the
-// last of the `target` contributions.
-__device__ __forceinline__ void column_done(const Segment& sg, u64* word, u64 total, unsigned target,
-                                            size_t at, int c) {
-  const u64 count = (total + (kCountUnit >> 1)) >> kCountShift;  // S may be negative: round, do not truncate
-  if ((unsigned)count != target) return;
-  const long long sfix = (long long)(total - (count << kCountShift));
-  const float v = (float)sfix * (1.f / (float)(1 << kFixShift)) + (sg.bias ? sg.bias[c] : 0.f);
-  reinterpret_cast<_Float16*>(sg.out16)[at] = (_Float16)v;
-  atomicExch(word, 0ull);  // result unused: a plain atomic store
-}
-
-// accumulate one UNCOUNTED value: fp32 atomic (operator launches) or fixed-point add (fused linear).
-// The pointer is cast to the global address space on purpose: through a generic pointer these
-// become FLAT atomics, and a flat operation anywhere upstream in the kernel's control-flow graph
-// makes the compiler treat vmcnt as out of order -- every later wait for a load turns into
-// vmcnt(0), including the codebook staging wait of the dense role (+0.3-0.6 us per launch).
-#define SQLLM_GLOBAL(T, p) reinterpret_cast<__attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p))
-__device__ __forceinline__ void acc_add(float* p, float v) {
-  __hip_atomic_fetch_add(SQLLM_GLOBAL(float, p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void acc_add(u64* p, float v) {
-  __hip_atomic_fetch_add(SQLLM_GLOBAL(u64, p), to_fixed(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Force every field of a segment descriptor into registers HERE (an empty asm statement that names the
-// value as a scalar INPUT operand: the loads feeding it must have completed; an in/out operand would
-// also hide where a pointer came from and turn every access through it into a FLAT instruction): the
-// compiler otherwise keeps a pointer per field and loads each one where it is first used, one
-// dependent scalar-load round trip (0.15 us) at a time.
-// (ONE statement for all of them: every asm statement waits for its own operands, and loads are not
-// moved above an earlier volatile asm.)
-#define SQLLM_SEG_OPERANDS(sg)                                                                                         \
-  "s"(sg.q), "s"(sg.y), "s"(sg.lut), "s"(sg.rows), "s"(sg.cols), "s"(sg.vals), "s"(sg.full_rows), "s"(sg.full_idx),    \
-  "s"(sg.bias), "s"(sg.out16), "s"(sg.gm.K), "s"(sg.gm.N), "s"(sg.gm.batch), "s"(sg.gm.col_tiles),                     \
-  "s"(sg.gm.units_total), "s"(sg.gm.units_per_wg), "s"(sg.gm.k_slices), "s"(sg.gm.dense_blocks),                       \
-  "s"(sg.gm.dense_block0), "s"(sg.gm.csr_blocks), "s"(sg.gm.topx_blocks), "s"(sg.gm.nnz), "s"(sg.gm.topX),             \
-  "s"(sg.gm.sparse_last)
 
 // ------------------------------------------------------------------------------------------------
 // Dense epilogue (shared by the dense-role variants): fold the 4 lane rows, then the waves through
@@ -935,359 +459,6 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
                                  , tl
 #endif
   );
-}
-
-// ------------------------------------------------------------------------------------------------
-// CSR role: one workgroup per chunk of kCsrChunk consecutive non-zeros (balanced by nnz, so a few
-// very long rows cost nothing extra -- the reference walks one row per thread serially,
-// quant_cuda_kernel.cu:1049-1058).
-//
-// The role is latency-bound (a chunk is 8 KiB of cols/vals), so it is organised as TWO rounds of
-// independent global loads and nothing else dependent on memory:
-//   round 1: this thread's cols/vals (coalesced) + ONE sampled probe of `rows` per thread
-//            (rows[t * S], S = ceil((N+1)/T)); two block-wide counts turn the probes into the
-//            sample intervals that contain the chunk's first and last non-zero;
-//   round 2: the x gather (needs cols) + the row pointers of every row between those two
-//            intervals, staged straight into LDS (needs the counts);
-//   then, LDS only: each non-zero finds its row by binary search in the staged pointers, products
-//   are summed per row in LDS, and each touched row leaves as one atomic.
-// ------------------------------------------------------------------------------------------------
-template <int T, int BT, typename XT, typename AT, bool XTMODE = false>
-__device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
-                                         const int* __restrict__ rows, const int* __restrict__ cols,
-                                         const float* __restrict__ vals, int nnz, int K, int N, int b0,
-                                         int nb, int chunk, float* lds, const Segment* lin, int lin_or_abl_bits = 0,
-                                         const float* __restrict__ xT = nullptr, int Bp = 0) {
-  constexpr bool LIN = sizeof(AT) == 8;
-  const int tid = threadIdx.x;
-  const int e0 = chunk * kCsrChunk;
-  int e1 = e0 + kCsrChunk;
-  if (e1 > nnz) e1 = nnz;
-  if (e0 >= e1) return;
-#ifdef SQLLM_ABLATION_BUILD
-  const int cabl = lin_or_abl_bits;  // 1 = skip the role, 2 = skip the flush, 4 = skip the accumulation
-  if (cabl & 1) return;
-#endif
-
-  // ---- round 1 ----
-  constexpr int EPT = kCsrChunk / T;  // non-zeros per thread: e0 + tid + T * i (coalesced)
-  int col[EPT];
-  float val[EPT];
-  // element of (thread, i): interleaved over the workgroup, or -- transposed-vec mode -- EPT runs of 64
-  // that are consecutive within a wave (so that only a wave's first and last row are shared with its
-  // neighbours)
-  auto elem = [&](int i) { return XTMODE ? e0 + (tid >> 6) * (64 * EPT) + 64 * i + (tid & 63) : e0 + tid + T * i; };
-#pragma unroll
-  for (int i = 0; i < EPT; ++i) {
-    int e = elem(i);
-    if (e > e1 - 1) e = e1 - 1;  // clamped re-read; masked below
-    col[i] = cols[e];
-    val[i] = vals[e];
-  }
-  const int S = (N + T) / T;  // sample stride: T samples cover rows[0 .. N]
-  const int si = tid * S;
-  const int probe = rows[si < N ? si : N];
-  // rows is non-decreasing with rows[0] = 0, so both predicates are true for a prefix of samples
-  const int cnt_lo = __syncthreads_count(si <= N && probe <= e0);
-  const int cnt_hi = __syncthreads_count(si <= N && probe <= e1 - 1);
-  const int c_lo = (cnt_lo > 0 ? cnt_lo - 1 : 0) * S;  // rows[c_lo] <= e0
-  int c_hi = cnt_hi * S;                                // rows[c_hi] > e1 - 1 (or the end)
-  if (c_hi > N) c_hi = N;
-  const int n = c_hi - c_lo + 1;  // staged row pointers rows[c_lo .. c_hi]; candidate rows: n - 1
-  const bool in_lds = n <= kCsrSpanMax;
-
-  // ---- round 2 ----
-  int* srows = reinterpret_cast<int*>(lds);  // [kCsrSpanMax]
-  float* sacc = lds + kCsrSpanMax;           // [kCsrSpanMax]
-  // the gather goes out first: the staging loop below waits for its own loads before it stores
-  float xg[EPT];
-#pragma unroll
-  for (int i = 0; i < EPT; ++i) xg[i] = XTMODE ? 0.f : (float)x[(size_t)b0 * K + col[i]];  // first batch row's gather
-  // Batch rows go through in groups of `g`: as many as have room for their n row sums each in the
-  // LDS accumulator (all of them for typical chunks, which span 50-100 rows), so a batched op
-  // pays the zero / accumulate / flush round and its barriers once, not once per row, and the x
-  // gathers of all rows are in flight together.
-  int g = 1;
-  if (in_lds) {
-    g = kCsrSpanMax / n;
-    if (g > nb) g = nb;
-    if (g < 1) g = 1;
-    for (int i = tid; i < n; i += T) srows[i] = rows[c_lo + i];
-    for (int i = tid; i < n * g; i += T) sacc[i] = 0.f;  // first group's sums (no barrier of its own)
-  }
-  // transposed-vec mode: sums of the pass's rows, tile[row][local column] (odd stride: the lanes of a
-  // wave -- one row each -- write one bank each), zeroed here, flushed coalesced along the columns
-  const bool use_tile = XTMODE && in_lds && n <= kCsrXtSpan;
-  const int TS = n | 1;
-  float* tile = lds + kCsrSpanMax;
-  if (use_tile) for (int i = tid; i < 64 * TS; i += T) tile[i] = 0.f;
-  __syncthreads();
-
-  // local row of each non-zero: largest i with rows[c_lo + i] <= e
-  int lr[EPT];
-#pragma unroll
-  for (int i = 0; i < EPT; ++i) {
-    const int e = elem(i);
-    int lo = 0, hi = n - 1;  // answer in [lo, hi): rows[c_lo + n - 1] > e by construction
-    if (hi < 1) hi = 1;
-    if (in_lds) {
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (srows[mid] <= e) lo = mid; else hi = mid;
-      }
-    } else {  // a chunk spanning > kCsrSpanMax rows (extremely sparse region): search in global memory
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (rows[c_lo + mid] <= e) lo = mid; else hi = mid;
-      }
-    }
-    lr[i] = (e < e1) ? lo : -1;
-  }
-  // segment structure of each 64-lane run of non-zeros (fixed for all batch rows): bit d = the lane
-  // 2^d below belongs to the same row (take its partial sum in scan step d), bit 6 = last lane of
-  // its row segment
-  unsigned seg[EPT];
-#pragma unroll
-  for (int i = 0; i < EPT; ++i) {
-    const int lane = tid & 63;
-    unsigned m = 0;
-#pragma unroll
-    for (int d = 0; d < 6; ++d) {
-      const int below = __shfl_up(lr[i], 1 << d, 64);
-      if (lane >= (1 << d) && below == lr[i]) m |= 1u << d;
-    }
-    const int above = __shfl_down(lr[i], 1, 64);
-    if (lane == 63 || above != lr[i]) m |= 64u;
-    seg[i] = m;
-  }
-
-  if constexpr (XTMODE) {
-    // Wide batches with a TRANSPOSED copy of vec (xT[k][row], written by sqllm_transpose_vec just
-    // before this launch): lane = batch row.  A wave walks its 64 * EPT consecutive non-zeros one
-    // at a time -- column, value and row come out of the owning lane with v_readlane, so control flow
-    // and addresses are scalar -- and every lane loads ITS row's element of xT[k] (one coalesced
-    // read per non-zero instead of one gather per row, 4 K bytes apart) and multiplies.  At the last
-    // non-zero of a row the lanes park their sums in tile[row][column]: a plain store, or an LDS add
-    // for the wave's first and last row (which the neighbouring waves may hold parts of).  The tile
-    // leaves with the lanes along the COLUMNS: coalesced atomics (lanes along the rows would hit
-    // one cache line each: measured 2.1 ms of a 4.6 ms launch at 2048 rows).
-    const int lane = tid & 63;
-    const bool row_ok = lane < nb;
-    const float* xl = xT + (b0 + (row_ok ? lane : 0));
-    unsigned long long ends[EPT], valid[EPT];
-    int n_valid = 0;
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      ends[i] = __ballot((seg[i] & 64u) && lr[i] >= 0);
-      valid[i] = __ballot(lr[i] >= 0);
-      n_valid += __builtin_popcountll(valid[i]);
-    }
-#pragma unroll
-    for (int i = 0; i + 1 < EPT; ++i)  // a row that runs on into the next run keeps its sum in the register
-      if ((valid[i + 1] & 1ull) && __builtin_amdgcn_readlane(lr[i], 63) == __builtin_amdgcn_readlane(lr[i + 1], 0)) ends[i] &= ~(1ull << 63);
-    float acc = 0.f;
-    bool first_seg = true;
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      constexpr int U = 32;  // loads in flight per wave: the role is latency-bound (a chunk is 1-2 workgroups per CU)
-      for (int j0 = 0; j0 < 64; j0 += U) {
-        if (((valid[i] >> j0) & 1ull) == 0) break;  // (valid lanes are a prefix)
-        float xv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int k = __builtin_amdgcn_readlane(col[i], j0 + u);
-          xv[u] = xl[(size_t)k * Bp];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int j = j0 + u;
-          const float v = ((valid[i] >> j) & 1ull) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val[i]), j)) : 0.f;
-          acc = __builtin_fmaf(v, xv[u], acc);
-          if ((ends[i] >> j) & 1ull) {
-            const int r = __builtin_amdgcn_readlane(lr[i], j);
-            if (use_tile) {
-              float* slot = tile + lane * TS + r;
-              if (first_seg || 64 * i + j == n_valid - 1) atomicAdd(slot, acc);  // LDS float atomic: lane by lane, twice per wave
-              else *slot = acc;
-            } else if (row_ok) {
-              acc_add(reinterpret_cast<float*>(y) + (size_t)(b0 + lane) * N + c_lo + r, acc);
-            }
-            first_seg = false;
-            acc = 0.f;
-          }
-        }
-      }
-    }
-    if (use_tile) {
-      __syncthreads();
-      const int nm1 = n - 1;
-      for (int idx = tid; idx < nm1 * nb; idx += T) {
-        const int b = idx / nm1, r = idx - b * nm1;
-        const float sum = tile[b * TS + r];
-        if (sum != 0.f) acc_add(reinterpret_cast<float*>(y) + (size_t)(b0 + b) * N + c_lo + r, sum);
-      }
-    }
-  } else {
-  const int nm1 = n - 1 > 0 ? n - 1 : 1;
-  for (int bs = 0; bs < nb; bs += g) {
-    const int gb = nb - bs < g ? nb - bs : g;
-    if (in_lds && bs > 0) {
-      for (int i = tid; i < n * gb; i += T) sacc[i] = 0.f;
-      __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      float xv[BT];
-#pragma unroll
-      for (int bb = 0; bb < BT; ++bb) {  // unconditional loads (rows past the group re-read its last row)
-        const int bi = bs + (bb < gb ? bb : gb - 1);
-        xv[bb] = (float)x[(size_t)(b0 + bi) * K + col[i]];
-      }
-      if (bs == 0) xv[0] = xg[i];
-      // a wave holds 64 consecutive non-zeros, i.e. a few whole or partial rows: segmented
-      // inclusive scan by row across the lanes, then ONE add per row segment (from its last lane)
-      // instead of 64 adds that collide on 2-3 addresses -- LDS float atomics to one address are
-      // executed one lane at a time (measured: 17 of 49 us of a batch-8 13B hybrid launch).
-      const int r = lr[i];
-      const unsigned sm = seg[i];
-#ifdef SQLLM_ABLATION_BUILD
-      if (cabl & 4) continue;
-#endif
-#pragma unroll
-      for (int bb = 0; bb < BT; ++bb) {
-        if (bb < gb) {
-          float p = val[i] * xv[bb];
-#pragma unroll
-          for (int d = 0; d < 6; ++d) {
-            const float up = __shfl_up(p, 1 << d, 64);
-            if (sm & (1u << d)) p += up;
-          }
-          if ((sm & 64u) && r >= 0) {
-            if (in_lds) atomicAdd(sacc + bb * n + r, p);
-            else acc_add(y + (size_t)(b0 + bs + bb) * N + c_lo + r, p);
-          }
-        }
-      }
-    }
-    if (in_lds) {
-      __syncthreads();
-#ifdef SQLLM_ABLATION_BUILD
-      if (cabl & 2) continue;
-#endif
-      for (int idx = tid; idx < nm1 * gb && n > 1; idx += T) {
-        const int bb = idx / nm1;
-        const int i = idx - bb * nm1;
-        const float sum = sacc[bb * n + i];
-        const size_t at = (size_t)(b0 + bs + bb) * N + c_lo + i;
-        if constexpr (LIN) {
-          // one COUNTED contribution per row this chunk holds a part of, whatever its value
-          const int r0 = srows[i], r1 = srows[i + 1];
-          if ((r0 > e0 ? r0 : e0) < (r1 < e1 ? r1 : e1)) {
-            const u64 mine = kCountUnit + to_fixed(sum);
-            const unsigned target = (unsigned)lin->gm.k_slices + (unsigned)csr_chunks_of_row(r0, r1);
-            column_done(*lin, y + at, atomicAdd(y + at, mine) + mine, target, at, c_lo + i);
-          }
-        } else {
-          if (sum != 0.f) acc_add(y + at, sum);
-        }
-      }
-      __syncthreads();
-    } else if constexpr (LIN) {
-      // (g == 1 here) the values went in uncounted, one add per non-zero; once they are
-      // acknowledged, count this chunk on every row it holds a part of
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      for (int i = tid; i < n - 1; i += T) {
-        const int r0 = rows[c_lo + i], r1 = rows[c_lo + i + 1];
-        if ((r0 > e0 ? r0 : e0) < (r1 < e1 ? r1 : e1)) {
-          const size_t at = (size_t)(b0 + bs) * N + c_lo + i;
-          const unsigned target = (unsigned)lin->gm.k_slices + (unsigned)csr_chunks_of_row(r0, r1);
-          column_done(*lin, y + at, atomicAdd(y + at, kCountUnit) + kCountUnit, target, at, c_lo + i);
-        }
-      }
-    }
-  }
-  }  // !XTMODE
-}
-
-// ------------------------------------------------------------------------------------------------
-// top-X role: full_rows is fp32 [K, topX] row-major; a workgroup takes kTopxRows consecutive k's,
-// i.e. one contiguous slab of kTopxRows*topX floats, and streams it coalesced (the reference keeps
-// topX of 128 lanes busy with stride-topX reads, quant_cuda_kernel.cu:1113-1118).
-// ------------------------------------------------------------------------------------------------
-template <int T, typename XT, typename AT>
-__device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
-                                          const float* __restrict__ full_rows,
-                                          const int* __restrict__ full_idx, int topX, int K, int N,
-                                          int b0, int nb, int slab, float* lds) {
-  const int tid = threadIdx.x;
-  const int k0 = slab * kTopxRows;
-  int k1 = k0 + kTopxRows;
-  if (k1 > K) k1 = K;
-  const int nel = (k1 - k0) * topX;
-  const float* fr = full_rows + (size_t)k0 * topX;
-  if (topX <= 16) {
-    // The usual case (the reference uses topX = 10).  Lane l of a 16-lane row owns column l (lanes
-    // >= topX idle) and the 32 lane rows of the workgroup take k0 + row, + 32, + 64, + 96: a wave
-    // reads 4 consecutive rows of the slab (contiguous), every thread keeps ONE partial sum in a
-    // register, two cross-lane adds fold the wave's 4 lane rows, the 8 waves meet in LDS through
-    // plain stores.  No LDS atomics (64 lanes on 10 addresses execute one lane at a time: that and
-    // two more barriers cost 0.6-0.9 us on the grouped 7B launches), one barrier per batch row.
-    static_assert(T == 512, "32 lane rows x 4 k's cover the 128-k slab");
-    const int c = tid & 15, krow = tid >> 4;  // krow 0..31
-    const int lane = tid & 63, wave = tid >> 6;
-    const bool live = c < topX;
-    float frv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int k = k0 + krow + 32 * i;
-      if (k > k1 - 1) k = k1 - 1;  // clamped re-read, masked below
-      frv[i] = live ? full_rows[(size_t)k * topX + c] : 0.f;
-    }
-    const int dst = live ? full_idx[c] : 0;
-    for (int b = 0; b < nb; ++b) {
-      const XT* xb = x + (size_t)(b0 + b) * K;
-      float p = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = k0 + krow + 32 * i;
-        p = __builtin_fmaf(frv[i], k < k1 ? (float)xb[k] : 0.f, p);
-      }
-      p += __shfl_xor(p, 16, 64);
-      p += __shfl_xor(p, 32, 64);
-      if (b > 0) __syncthreads();  // the previous batch row's sums have been read
-      if (lane < 16) lds[wave * 16 + lane] = p;
-      __syncthreads();
-      if (tid < topX) {
-        float sum = 0.f;
-#pragma unroll
-        for (int w = 0; w < T / 64; ++w) sum += lds[w * 16 + tid];
-        acc_add(y + (size_t)(b0 + b) * N + dst, sum);
-      }
-    }
-    return;
-  }
-  const bool in_lds = topX <= kTopxLds;
-  float* sacc = lds;
-  for (int b = 0; b < nb; ++b) {
-    const XT* xb = x + (size_t)(b0 + b) * K + k0;
-    AT* yb = y + (size_t)(b0 + b) * N;
-    if (in_lds) {
-      for (int c = tid; c < topX; c += T) sacc[c] = 0.f;
-      __syncthreads();
-    }
-    for (int e = tid; e < nel; e += T) {
-      const int kk = e / topX;
-      const int c = e - kk * topX;
-      const float p = fr[e] * (float)xb[kk];
-      if (in_lds) atomicAdd(sacc + c, p); else acc_add(yb + full_idx[c], p);
-    }
-    if (in_lds) {
-      __syncthreads();
-      for (int c = tid; c < topX; c += T) acc_add(yb + full_idx[c], sacc[c]);
-      __syncthreads();
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------

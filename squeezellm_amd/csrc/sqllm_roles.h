@@ -1,0 +1,363 @@
+// sqllm_roles.h -- the sparse roles of a launch (CSR chunks balanced by nnz; top-X row slabs), shared
+// by the fused kernels of sqllm_kernels.hip and the streaming kernel of sqllm_stream.hip.
+// Reference arithmetic: squeezellm/quant_cuda_kernel.cu:1040-1089 (SPMV_ATOMIC[_BATCHED]),
+// :1092-1164 (DenseMatVecKernel[Batched]).
+#pragma once
+#include "sqllm_decode.h"
+
+namespace sqllm {
+
+// ------------------------------------------------------------------------------------------------
+// CSR role: one workgroup per chunk of kCsrChunk consecutive non-zeros (balanced by nnz, so a few
+// very long rows cost nothing extra -- the reference walks one row per thread serially,
+// quant_cuda_kernel.cu:1049-1058).
+//
+// The role is latency-bound (a chunk is 8 KiB of cols/vals), so it is organised as TWO rounds of
+// independent global loads and nothing else dependent on memory:
+//   round 1: this thread's cols/vals (coalesced) + ONE sampled probe of `rows` per thread
+//            (rows[t * S], S = ceil((N+1)/T)); two block-wide counts turn the probes into the
+//            sample intervals that contain the chunk's first and last non-zero;
+//   round 2: the x gather (needs cols) + the row pointers of every row between those two
+//            intervals, staged straight into LDS (needs the counts);
+//   then, LDS only: each non-zero finds its row by binary search in the staged pointers, products
+//   are summed per row in LDS, and each touched row leaves as one atomic.
+// ------------------------------------------------------------------------------------------------
+template <int T, int BT, typename XT, typename AT, bool XTMODE = false>
+__device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
+                                         const int* __restrict__ rows, const int* __restrict__ cols,
+                                         const float* __restrict__ vals, int nnz, int K, int N, int b0,
+                                         int nb, int chunk, float* lds, const Segment* lin, int lin_or_abl_bits = 0,
+                                         const float* __restrict__ xT = nullptr, int Bp = 0) {
+  constexpr bool LIN = sizeof(AT) == 8;
+  const int tid = threadIdx.x;
+  const int e0 = chunk * kCsrChunk;
+  int e1 = e0 + kCsrChunk;
+  if (e1 > nnz) e1 = nnz;
+  if (e0 >= e1) return;
+#ifdef SQLLM_ABLATION_BUILD
+  const int cabl = lin_or_abl_bits;  // 1 = skip the role, 2 = skip the flush, 4 = skip the accumulation
+  if (cabl & 1) return;
+#endif
+
+  // ---- round 1 ----
+  constexpr int EPT = kCsrChunk / T;  // non-zeros per thread: e0 + tid + T * i (coalesced)
+  int col[EPT];
+  float val[EPT];
+  // element of (thread, i): interleaved over the workgroup, or -- transposed-vec mode -- EPT runs of 64
+  // that are consecutive within a wave (so that only a wave's first and last row are shared with its
+  // neighbours)
+  auto elem = [&](int i) { return XTMODE ? e0 + (tid >> 6) * (64 * EPT) + 64 * i + (tid & 63) : e0 + tid + T * i; };
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    int e = elem(i);
+    if (e > e1 - 1) e = e1 - 1;  // clamped re-read; masked below
+    col[i] = cols[e];
+    val[i] = vals[e];
+  }
+  const int S = (N + T) / T;  // sample stride: T samples cover rows[0 .. N]
+  const int si = tid * S;
+  const int probe = rows[si < N ? si : N];
+  // rows is non-decreasing with rows[0] = 0, so both predicates are true for a prefix of samples
+  const int cnt_lo = __syncthreads_count(si <= N && probe <= e0);
+  const int cnt_hi = __syncthreads_count(si <= N && probe <= e1 - 1);
+  const int c_lo = (cnt_lo > 0 ? cnt_lo - 1 : 0) * S;  // rows[c_lo] <= e0
+  int c_hi = cnt_hi * S;                                // rows[c_hi] > e1 - 1 (or the end)
+  if (c_hi > N) c_hi = N;
+  const int n = c_hi - c_lo + 1;  // staged row pointers rows[c_lo .. c_hi]; candidate rows: n - 1
+  const bool in_lds = n <= kCsrSpanMax;
+
+  // ---- round 2 ----
+  int* srows = reinterpret_cast<int*>(lds);  // [kCsrSpanMax]
+  float* sacc = lds + kCsrSpanMax;           // [kCsrSpanMax]
+  // the gather goes out first: the staging loop below waits for its own loads before it stores
+  float xg[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) xg[i] = XTMODE ? 0.f : (float)x[(size_t)b0 * K + col[i]];  // first batch row's gather
+  // Batch rows go through in groups of `g`: as many as have room for their n row sums each in the
+  // LDS accumulator (all of them for typical chunks, which span 50-100 rows), so a batched op
+  // pays the zero / accumulate / flush round and its barriers once, not once per row, and the x
+  // gathers of all rows are in flight together.
+  int g = 1;
+  if (in_lds) {
+    g = kCsrSpanMax / n;
+    if (g > nb) g = nb;
+    if (g < 1) g = 1;
+    for (int i = tid; i < n; i += T) srows[i] = rows[c_lo + i];
+    for (int i = tid; i < n * g; i += T) sacc[i] = 0.f;  // first group's sums (no barrier of its own)
+  }
+  // transposed-vec mode: sums of the pass's rows, tile[row][local column] (odd stride: the lanes of a
+  // wave -- one row each -- write one bank each), zeroed here, flushed coalesced along the columns
+  const bool use_tile = XTMODE && in_lds && n <= kCsrXtSpan;
+  const int TS = n | 1;
+  float* tile = lds + kCsrSpanMax;
+  if (use_tile) for (int i = tid; i < 64 * TS; i += T) tile[i] = 0.f;
+  __syncthreads();
+
+  // local row of each non-zero: largest i with rows[c_lo + i] <= e
+  int lr[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = elem(i);
+    int lo = 0, hi = n - 1;  // answer in [lo, hi): rows[c_lo + n - 1] > e by construction
+    if (hi < 1) hi = 1;
+    if (in_lds) {
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (srows[mid] <= e) lo = mid; else hi = mid;
+      }
+    } else {  // a chunk spanning > kCsrSpanMax rows (extremely sparse region): search in global memory
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rows[c_lo + mid] <= e) lo = mid; else hi = mid;
+      }
+    }
+    lr[i] = (e < e1) ? lo : -1;
+  }
+  // segment structure of each 64-lane run of non-zeros (fixed for all batch rows): bit d = the lane
+  // 2^d below belongs to the same row (take its partial sum in scan step d), bit 6 = last lane of
+  // its row segment
+  unsigned seg[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int lane = tid & 63;
+    unsigned m = 0;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      const int below = __shfl_up(lr[i], 1 << d, 64);
+      if (lane >= (1 << d) && below == lr[i]) m |= 1u << d;
+    }
+    const int above = __shfl_down(lr[i], 1, 64);
+    if (lane == 63 || above != lr[i]) m |= 64u;
+    seg[i] = m;
+  }
+
+  if constexpr (XTMODE) {
+    // Wide batches with a TRANSPOSED copy of vec (xT[k][row], written by sqllm_transpose_vec just
+    // before this launch): lane = batch row.  A wave walks its 64 * EPT consecutive non-zeros one
+    // at a time -- column, value and row come out of the owning lane with v_readlane, so control flow
+    // and addresses are scalar -- and every lane loads ITS row's element of xT[k] (one coalesced
+    // read per non-zero instead of one gather per row, 4 K bytes apart) and multiplies.  At the last
+    // non-zero of a row the lanes park their sums in tile[row][column]: a plain store, or an LDS add
+    // for the wave's first and last row (which the neighbouring waves may hold parts of).  The tile
+    // leaves with the lanes along the COLUMNS: coalesced atomics (lanes along the rows would hit
+    // one cache line each: measured 2.1 ms of a 4.6 ms launch at 2048 rows).
+    const int lane = tid & 63;
+    const bool row_ok = lane < nb;
+    const float* xl = xT + (b0 + (row_ok ? lane : 0));
+    unsigned long long ends[EPT], valid[EPT];
+    int n_valid = 0;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      ends[i] = __ballot((seg[i] & 64u) && lr[i] >= 0);
+      valid[i] = __ballot(lr[i] >= 0);
+      n_valid += __builtin_popcountll(valid[i]);
+    }
+#pragma unroll
+    for (int i = 0; i + 1 < EPT; ++i)  // a row that runs on into the next run keeps its sum in the register
+      if ((valid[i + 1] & 1ull) && __builtin_amdgcn_readlane(lr[i], 63) == __builtin_amdgcn_readlane(lr[i + 1], 0)) ends[i] &= ~(1ull << 63);
+    float acc = 0.f;
+    bool first_seg = true;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      constexpr int U = 32;  // loads in flight per wave: the role is latency-bound (a chunk is 1-2 workgroups per CU)
+      for (int j0 = 0; j0 < 64; j0 += U) {
+        if (((valid[i] >> j0) & 1ull) == 0) break;  // (valid lanes are a prefix)
+        float xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = __builtin_amdgcn_readlane(col[i], j0 + u);
+          xv[u] = xl[(size_t)k * Bp];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = j0 + u;
+          const float v = ((valid[i] >> j) & 1ull) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val[i]), j)) : 0.f;
+          acc = __builtin_fmaf(v, xv[u], acc);
+          if ((ends[i] >> j) & 1ull) {
+            const int r = __builtin_amdgcn_readlane(lr[i], j);
+            if (use_tile) {
+              float* slot = tile + lane * TS + r;
+              if (first_seg || 64 * i + j == n_valid - 1) atomicAdd(slot, acc);  // LDS float atomic: lane by lane, twice per wave
+              else *slot = acc;
+            } else if (row_ok) {
+              acc_add(reinterpret_cast<float*>(y) + (size_t)(b0 + lane) * N + c_lo + r, acc);
+            }
+            first_seg = false;
+            acc = 0.f;
+          }
+        }
+      }
+    }
+    if (use_tile) {
+      __syncthreads();
+      const int nm1 = n - 1;
+      for (int idx = tid; idx < nm1 * nb; idx += T) {
+        const int b = idx / nm1, r = idx - b * nm1;
+        const float sum = tile[b * TS + r];
+        if (sum != 0.f) acc_add(reinterpret_cast<float*>(y) + (size_t)(b0 + b) * N + c_lo + r, sum);
+      }
+    }
+  } else {
+  const int nm1 = n - 1 > 0 ? n - 1 : 1;
+  for (int bs = 0; bs < nb; bs += g) {
+    const int gb = nb - bs < g ? nb - bs : g;
+    if (in_lds && bs > 0) {
+      for (int i = tid; i < n * gb; i += T) sacc[i] = 0.f;
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      float xv[BT];
+#pragma unroll
+      for (int bb = 0; bb < BT; ++bb) {  // unconditional loads (rows past the group re-read its last row)
+        const int bi = bs + (bb < gb ? bb : gb - 1);
+        xv[bb] = (float)x[(size_t)(b0 + bi) * K + col[i]];
+      }
+      if (bs == 0) xv[0] = xg[i];
+      // a wave holds 64 consecutive non-zeros, i.e. a few whole or partial rows: segmented
+      // inclusive scan by row across the lanes, then ONE add per row segment (from its last lane)
+      // instead of 64 adds that collide on 2-3 addresses -- LDS float atomics to one address are
+      // executed one lane at a time (measured: 17 of 49 us of a batch-8 13B hybrid launch).
+      const int r = lr[i];
+      const unsigned sm = seg[i];
+#ifdef SQLLM_ABLATION_BUILD
+      if (cabl & 4) continue;
+#endif
+#pragma unroll
+      for (int bb = 0; bb < BT; ++bb) {
+        if (bb < gb) {
+          float p = val[i] * xv[bb];
+#pragma unroll
+          for (int d = 0; d < 6; ++d) {
+            const float up = __shfl_up(p, 1 << d, 64);
+            if (sm & (1u << d)) p += up;
+          }
+          if ((sm & 64u) && r >= 0) {
+            if (in_lds) atomicAdd(sacc + bb * n + r, p);
+            else acc_add(y + (size_t)(b0 + bs + bb) * N + c_lo + r, p);
+          }
+        }
+      }
+    }
+    if (in_lds) {
+      __syncthreads();
+#ifdef SQLLM_ABLATION_BUILD
+      if (cabl & 2) continue;
+#endif
+      for (int idx = tid; idx < nm1 * gb && n > 1; idx += T) {
+        const int bb = idx / nm1;
+        const int i = idx - bb * nm1;
+        const float sum = sacc[bb * n + i];
+        const size_t at = (size_t)(b0 + bs + bb) * N + c_lo + i;
+        if constexpr (LIN) {
+          // one COUNTED contribution per row this chunk holds a part of, whatever its value
+          const int r0 = srows[i], r1 = srows[i + 1];
+          if ((r0 > e0 ? r0 : e0) < (r1 < e1 ? r1 : e1)) {
+            const u64 mine = kCountUnit + to_fixed(sum);
+            const unsigned target = (unsigned)lin->gm.k_slices + (unsigned)csr_chunks_of_row(r0, r1);
+            column_done(*lin, y + at, atomicAdd(y + at, mine) + mine, target, at, c_lo + i);
+          }
+        } else {
+          if (sum != 0.f) acc_add(y + at, sum);
+        }
+      }
+      __syncthreads();
+    } else if constexpr (LIN) {
+      // (g == 1 here) the values went in uncounted, one add per non-zero; once they are
+      // acknowledged, count this chunk on every row it holds a part of
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      for (int i = tid; i < n - 1; i += T) {
+        const int r0 = rows[c_lo + i], r1 = rows[c_lo + i + 1];
+        if ((r0 > e0 ? r0 : e0) < (r1 < e1 ? r1 : e1)) {
+          const size_t at = (size_t)(b0 + bs) * N + c_lo + i;
+          const unsigned target = (unsigned)lin->gm.k_slices + (unsigned)csr_chunks_of_row(r0, r1);
+          column_done(*lin, y + at, atomicAdd(y + at, kCountUnit) + kCountUnit, target, at, c_lo + i);
+        }
+      }
+    }
+  }
+  }  // !XTMODE
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-X role: full_rows is fp32 [K, topX] row-major; a workgroup takes kTopxRows consecutive k's,
+// i.e. one contiguous slab of kTopxRows*topX floats, and streams it coalesced (the reference keeps
+// topX of 128 lanes busy with stride-topX reads, quant_cuda_kernel.cu:1113-1118).
+// ------------------------------------------------------------------------------------------------
+template <int T, typename XT, typename AT>
+__device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
+                                          const float* __restrict__ full_rows,
+                                          const int* __restrict__ full_idx, int topX, int K, int N,
+                                          int b0, int nb, int slab, float* lds) {
+  const int tid = threadIdx.x;
+  const int k0 = slab * kTopxRows;
+  int k1 = k0 + kTopxRows;
+  if (k1 > K) k1 = K;
+  const int nel = (k1 - k0) * topX;
+  const float* fr = full_rows + (size_t)k0 * topX;
+  if (topX <= 16) {
+    // The usual case (the reference uses topX = 10).  Lane l of a 16-lane row owns column l (lanes
+    // >= topX idle) and the 32 lane rows of the workgroup take k0 + row, + 32, + 64, + 96: a wave
+    // reads 4 consecutive rows of the slab (contiguous), every thread keeps ONE partial sum in a
+    // register, two cross-lane adds fold the wave's 4 lane rows, the 8 waves meet in LDS through
+    // plain stores.  No LDS atomics (64 lanes on 10 addresses execute one lane at a time: that and
+    // two more barriers cost 0.6-0.9 us on the grouped 7B launches), one barrier per batch row.
+    static_assert(T == 512, "32 lane rows x 4 k's cover the 128-k slab");
+    const int c = tid & 15, krow = tid >> 4;  // krow 0..31
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool live = c < topX;
+    float frv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int k = k0 + krow + 32 * i;
+      if (k > k1 - 1) k = k1 - 1;  // clamped re-read, masked below
+      frv[i] = live ? full_rows[(size_t)k * topX + c] : 0.f;
+    }
+    const int dst = live ? full_idx[c] : 0;
+    for (int b = 0; b < nb; ++b) {
+      const XT* xb = x + (size_t)(b0 + b) * K;
+      float p = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = k0 + krow + 32 * i;
+        p = __builtin_fmaf(frv[i], k < k1 ? (float)xb[k] : 0.f, p);
+      }
+      p += __shfl_xor(p, 16, 64);
+      p += __shfl_xor(p, 32, 64);
+      if (b > 0) __syncthreads();  // the previous batch row's sums have been read
+      if (lane < 16) lds[wave * 16 + lane] = p;
+      __syncthreads();
+      if (tid < topX) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < T / 64; ++w) sum += lds[w * 16 + tid];
+        acc_add(y + (size_t)(b0 + b) * N + dst, sum);
+      }
+    }
+    return;
+  }
+  const bool in_lds = topX <= kTopxLds;
+  float* sacc = lds;
+  for (int b = 0; b < nb; ++b) {
+    const XT* xb = x + (size_t)(b0 + b) * K + k0;
+    AT* yb = y + (size_t)(b0 + b) * N;
+    if (in_lds) {
+      for (int c = tid; c < topX; c += T) sacc[c] = 0.f;
+      __syncthreads();
+    }
+    for (int e = tid; e < nel; e += T) {
+      const int kk = e / topX;
+      const int c = e - kk * topX;
+      const float p = fr[e] * (float)xb[kk];
+      if (in_lds) atomicAdd(sacc + c, p); else acc_add(yb + full_idx[c], p);
+    }
+    if (in_lds) {
+      __syncthreads();
+      for (int c = tid; c < topX; c += T) acc_add(yb + full_idx[c], sacc[c]);
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace sqllm

@@ -1,0 +1,449 @@
+// sqllm_stream.hip -- the batch-1 dense matvec as a STREAMING kernel: one resident round of
+// long-lived workgroups, each walking a contiguous range of the launch's weights behind a rolling
+// prefetch.  Same arithmetic contract as sqllm_fused_matvec (sqllm_kernels.hip; reference
+// squeezellm/quant_cuda_kernel.cu:741-880), same tile shape, same lookup tables -- a different
+// life-cycle of the workgroups.
+//
+// Why (round 3 measurements, tools/experiments/dispatch_ramp.hip, tools/timeline.py, tools/sweep.py
+// --ablate): the fused kernel with its decode compiled OUT takes as long as with it (7B shapes,
+// 4-bit: 5.2 / 9.4 / 14.6 / 8.9 us without any decode against 5.3 / 9.3 / 14.1 / 8.9 us with), and
+// 1.8-2.4x as long as a loads-only calibration kernel over the same bytes (2.9 / 5.8 / 10.3 / 5.4 us).
+// It is not bound by instruction issue at these sizes but by the life-cycle of its workgroups: a
+// workgroup lives ~4-6 us whatever it does -- argument fetch, codebook fetch + barrier, first-byte
+// latency of the one chunk of loads it issues, the cross-wave combine, the atomics -- holds no load
+// in flight for half of that, and the larger launches need two rounds of such workgroups.
+//
+// Here:
+//   * the dense work of a launch (all its ops: q/k/v or gate/up share a launch) is the FLATTENED space
+//     of (op, 64-column tile, step of 4 units); it is cut into equal contiguous ranges, one per
+//     workgroup, as many workgroups as are resident at once (minus the sparse-role workgroups): one
+//     round, nobody waits for a slot, nobody is short;
+//   * a range may cross tile (and op) boundaries: its at most NT tiles are "pieces"; the codebooks
+//     of ALL pieces are staged up front, behind ONE barrier, and the lookups select the piece's table
+//     through a bit that rides in the index bytes (4-bit: free) or a per-piece base (3-bit);
+//   * the waves of a workgroup interleave steps over the whole range and keep RING steps of loads in
+//     flight across piece boundaries: loads are issued again the moment a ring slot has been decoded
+//     (raw buffer loads: steps past the end of the range read a null descriptor -- zeros, no memory
+//     access, no branch; lanes past a ragged end are out of the descriptor's range the same way);
+//   * partial sums of a piece are parked in the wave's LDS slab when the wave moves on to the next
+//     piece; ONE barrier at the end, then wave p sums piece p's slabs: one atomic per column and piece.
+// The sparse roles (CSR chunks, top-X slabs) are the workgroups in front of the dense ones, unchanged.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+
+#include "sqllm_decode.h"
+#include "sqllm_roles.h"
+
+namespace sqllm {
+
+template <int BITS> struct StreamCfg;
+template <> struct StreamCfg<4> {
+  static constexpr int kTableBytes = 8192;  // 2 column pairs x 16 entries x 256 B (two copies of 16 column groups)
+  static constexpr int kPieces = kStreamPieces4;
+  static constexpr int kRing = 2;           // ring slots; a slot = TWO steps sharing one x register
+  static constexpr int kWgPerCu = 3;        // 80 VGPRs (the ring + the piece terms do not fit 64 without spills)
+};
+template <> struct StreamCfg<3> {
+  static constexpr int kTableBytes = 32768;  // 4 lane columns x 64 pair entries x 128 B
+  static constexpr int kPieces = kStreamPieces3;
+  static constexpr int kRing = 2;            // ring slots; a slot = one step (3 rows, two x registers)
+  static constexpr int kWgPerCu = 2;
+};
+
+constexpr int stream_lds_bytes(int bits) {
+  const int dense = (bits == 4 ? StreamCfg<4>::kTableBytes * StreamCfg<4>::kPieces + StreamCfg<4>::kPieces * kWaves * 256
+                               : StreamCfg<3>::kTableBytes * StreamCfg<3>::kPieces + StreamCfg<3>::kPieces * kWaves * 256);
+  const int sparse = 4 * cmax(2 * kCsrSpanMax, kTopxLds);
+  return dense > sparse ? dense : sparse;
+}
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 load_b128_nt(rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2 /* nt */));
+}
+__device__ __forceinline__ float load_b32(rsrc_t r, uint32_t voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+
+// 4-bit step with a table selector: `tmask` = (piece << 5) in every byte, OR-ed into the nibble bytes
+// by the same v_and_or that masks them, so that byte 1 of a lookup address is nibble + 32 * piece and
+// the address lands in the piece's 8 KiB table.  One column PAIR at a time (16 live lookups).
+template <int XL, int ABL>
+__device__ __forceinline__ void step4_stream(const u32x4& slot, float xv, uint32_t lane_off, uint32_t tmask,
+                                             f32x2 (&acc)[2]) {
+  uint32_t t[4] = {slot.x, slot.y, slot.z, slot.w};
+  SQLLM_PIN4(t[0], t[1], t[2], t[3]);
+  if constexpr (ABL & 2) {
+    acc[0].x += __builtin_bit_cast(float, t[0] ^ t[1]) * xv;
+    acc[1].x += __builtin_bit_cast(float, t[2] ^ t[3]) * xv;
+    return;
+  }
+  const float xa[1] = {xv};
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) {
+    f32x2 vp[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = 2 * jp + h;
+      const uint32_t lo = (t[j] & 0x0F0F0F0Fu) | tmask;
+      const uint32_t hi = ((t[j] >> 4) & 0x0F0F0F0Fu) | tmask;
+      const int off = jp * 4096 + h * 128;
+      float e[8];
+      e[0] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0400u) + off);
+      e[1] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0400u) + off);
+      e[2] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0500u) + off);
+      e[3] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0500u) + off);
+      e[4] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0600u) + off);
+      e[5] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0600u) + off);
+      e[6] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0700u) + off);
+      e[7] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0700u) + off);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (h) vp[i].y = e[i]; else vp[i].x = e[i];
+      }
+    }
+    f32x2 a1[1] = {acc[jp]};
+    fma_pair<1, XL>(vp, xa, a1);
+    acc[jp] = a1[0];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// One piece of a workgroup's range = a 64-column tile of one op of the launch: the op's operands and the tile's
+// first column (all wave-uniform).
+template <int BITS>
+__device__ __forceinline__ void piece_terms(const StreamArgs& sa, int T, int i16, int grp, const char*& q, float*& y,
+                                            const float*& lut, int& N, int& col0) {
+  int s = 0;
+  if (sa.n_seg > 1 && T >= sa.seg[1].tile0) s = 1;
+  if (sa.n_seg > 2 && T >= sa.seg[2].tile0) s = 2;
+  if (sa.n_seg > 3 && T >= sa.seg[3].tile0) s = 3;
+  q = reinterpret_cast<const char*>(s == 0 ? sa.seg[0].q : s == 1 ? sa.seg[1].q : s == 2 ? sa.seg[2].q : sa.seg[3].q);
+  y = s == 0 ? sa.seg[0].y : s == 1 ? sa.seg[1].y : s == 2 ? sa.seg[2].y : sa.seg[3].y;
+  lut = s == 0 ? sa.seg[0].lut : s == 1 ? sa.seg[1].lut : s == 2 ? sa.seg[2].lut : sa.seg[3].lut;
+  N = s == 0 ? sa.seg[0].N : s == 1 ? sa.seg[1].N : s == 2 ? sa.seg[2].N : sa.seg[3].N;
+  const int tile0 = s == 0 ? 0 : s == 1 ? sa.seg[1].tile0 : s == 2 ? sa.seg[2].tile0 : sa.seg[3].tile0;
+  col0 = (T - tile0) * kTileN;
+}
+
+// this lane's byte offset inside a step of a piece: 4-bit: its row of the step's 4 + its 16 bytes of the row; 3-bit: its 16 bytes
+template <int BITS>
+__device__ __forceinline__ uint32_t lane_offset_in_step(int N, int col0, int i16, int grp) {
+  int cidx = col0 / 4 + i16;
+  if (cidx > N / 4 - 1) cidx = N / 4 - 1;  // lanes past N re-read the row's last 16 bytes (never accumulated)
+  return (BITS == 4 ? (uint32_t)grp * (4u * (uint32_t)N) : 0u) + 16u * (uint32_t)cidx;
+}
+
+#define SQLLM_GPTR(T, p) reinterpret_cast<const __attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p))
+
+template <int BITS, int ABL>
+__device__ __forceinline__ void stream_dense(const StreamArgs& sa, int bid, char* lds) {
+  using F = Fmt<BITS>;
+  using C = StreamCfg<BITS>;
+  constexpr int WAVES = kWaves;
+  constexpr int NT = C::kPieces;
+  constexpr int R = F::kRows;
+  constexpr int RING = C::kRing;
+  constexpr int SPS = (BITS == 4) ? 2 : 1;  // steps per ring slot
+  constexpr int NX = (BITS == 4) ? 1 : 2;   // x registers per ring slot
+  static_assert(WAVES == 8, "staging assigns table rows by wave");
+  static_assert(NT == 2 || NT == 3, "three named pieces");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, grp = lane >> 4;
+
+  // ---- this workgroup's range of steps, its pieces (all wave-uniform) ----
+  const int S = sa.steps_per_tile;
+  const int u_beg = bid * sa.steps_per_wg;
+  int u_end = u_beg + sa.steps_per_wg;
+  if (u_end > sa.total_steps) u_end = sa.total_steps;
+  if (u_beg >= u_end) return;
+  const int T0 = __builtin_amdgcn_readfirstlane((unsigned)u_beg / (unsigned)S);
+  const int T1 = __builtin_amdgcn_readfirstlane((unsigned)(u_end - 1) / (unsigned)S);
+  const int np = T1 - T0 + 1;      // <= NT (the host's plan guarantees it)
+  const int rg0 = u_beg - T0 * S;  // first step's position inside tile T0
+  const rsrc_t x_rsrc = make_rsrc(sa.x, 4u * (uint32_t)sa.K);
+#ifdef SQLLM_ABLATION_BUILD
+  unsigned long long* tl = sa.probe ? sa.probe + 8ull * blockIdx.x : nullptr;
+  if (tl && tid == 0) tl[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  // Per-piece terms live in plain named scalars (p0_*, p1_*, p2_*), selected by compares: an array or a
+  // struct selected by the run-time piece index ends up as an indexed load from scratch memory.
+  // (pieces past the last one repeat it: staged twice, never decoded, never flushed)
+#define SQLLM_PIECE(I)                                                                                                  \
+  const char* p##I##_q; float* p##I##_y; const float* p##I##_lut; int p##I##_N, p##I##_col0;                              \
+  piece_terms<BITS>(sa, (T0 + I > T1 ? T1 : T0 + I), i16, grp, p##I##_q, p##I##_y, p##I##_lut, p##I##_N, p##I##_col0)
+  SQLLM_PIECE(0);
+  SQLLM_PIECE(1);
+  SQLLM_PIECE(2);  // (NT == 2: never selected)
+#undef SQLLM_PIECE
+#define SQLLM_PC(p, f) ((p) == 0 ? p0_##f : ((p) == 1 || NT < 3) ? p1_##f : p2_##f)
+
+  // ---- cursors: (piece, step inside the piece's tile, global step) of the next step to LOAD / to DECODE.
+  //      The waves interleave steps over the whole range: wave w takes u_beg + w, + WAVES, ...
+  //      The load cursor carries its piece's addressing terms along and re-selects them only when it
+  //      crosses into the next piece (scalar control flow without memory operations).
+  int l_p = 0, l_rg = rg0 + wave, l_u = u_beg + wave;
+  while (l_rg >= S) { l_rg -= S; ++l_p; }
+  int d_p = l_p, d_rg = l_rg, d_u = l_u;
+  const char* l_q = SQLLM_PC(l_p, q);
+  uint32_t l_rb = 4u * (uint32_t)SQLLM_PC(l_p, N);  // bytes per qweight row of the load cursor's piece
+  uint32_t l_vlane = lane_offset_in_step<BITS>(SQLLM_PC(l_p, N), SQLLM_PC(l_p, col0), i16, grp);
+
+  // ---- ring of loads ----
+  u32x4 w[RING][SPS][R];
+  float xs[RING][NX];
+  // Loads are unconditional (a load under a branch makes the compiler wait for everything in flight at the
+  // join).  A step past the end of the range ("dead": the ring runs ahead of the decode) reads 16 bytes per lane
+  // of vec instead -- always cache-resident, never decoded; its x comes back as zeros (out of the
+  // descriptor's range).  x: 4-bit: lane i of a 16-lane row holds x[8 * unit + (i & 7)], lanes 0-7 for the
+  // slot's first step, lanes 8-15 for its second; 3-bit: two registers, x[32 * unit + i] and x[32 * unit + 16 + i].
+  const char* dead_q = reinterpret_cast<const char*>(sa.x);
+#define SQLLM_ISSUE(r)                                                                                            \
+  do {                                                                                                            \
+    uint32_t xoff_[SPS];                                                                                          \
+    _Pragma("unroll") for (int s_ = 0; s_ < SPS; ++s_) {                                                          \
+      const bool live_ = l_u < u_end;                                                                             \
+      const char* base_ = live_ ? l_q : dead_q;                                                                   \
+      const uint32_t unit_ = 4u * (uint32_t)l_rg + (uint32_t)grp;                                                 \
+      uint32_t voff_;                                                                                             \
+      if constexpr (BITS == 4) {                                                                                  \
+        voff_ = l_vlane + (uint32_t)l_rg * (4u * l_rb);                                                           \
+      } else { /* a tile's last step may be ragged (K / 32 not a multiple of 4): such lanes re-read the last unit */ \
+        uint32_t uc_ = unit_;                                                                                     \
+        if (uc_ > (uint32_t)sa.units_total - 1u) uc_ = (uint32_t)sa.units_total - 1u;                             \
+        voff_ = l_vlane + uc_ * (3u * l_rb);                                                                      \
+      }                                                                                                           \
+      voff_ = live_ ? voff_ : 16u * (uint32_t)(i16 & 7);                                                          \
+      const uint32_t rb_ = live_ ? l_rb : 0u;                                                                     \
+      _Pragma("unroll") for (int rr_ = 0; rr_ < R; ++rr_)                                                         \
+        w[r][s_][rr_] = __builtin_nontemporal_load(SQLLM_GPTR(u32x4, base_ + (voff_ + (uint32_t)rr_ * rb_)));    \
+      xoff_[s_] = live_ ? 4u * ((uint32_t)F::kK * unit_) : 0xFFFFFF00u; /* (ragged lanes: past K, zeros) */       \
+      l_u += WAVES;                                                                                               \
+      l_rg += WAVES;                                                                                              \
+      if (l_rg >= S) {                                                                                            \
+        while (l_rg >= S) { l_rg -= S; ++l_p; }                                                                   \
+        const int lp_ = l_p < NT ? l_p : NT - 1;                                                                  \
+        l_q = SQLLM_PC(lp_, q);                                                                                   \
+        l_rb = 4u * (uint32_t)SQLLM_PC(lp_, N);                                                                   \
+        l_vlane = lane_offset_in_step<BITS>(SQLLM_PC(lp_, N), SQLLM_PC(lp_, col0), i16, grp);                     \
+      }                                                                                                           \
+    }                                                                                                             \
+    if constexpr (BITS == 4) {                                                                                    \
+      xs[r][0] = load_b32(x_rsrc, ((i16 & 8) ? xoff_[SPS - 1] : xoff_[0]) + 4u * (uint32_t)(i16 & 7));            \
+    } else {                                                                                                      \
+      xs[r][0] = load_b32(x_rsrc, xoff_[0] + 4u * (uint32_t)i16);                                                 \
+      xs[r][NX - 1] = load_b32(x_rsrc, xoff_[0] + 4u * (uint32_t)(i16 + 16));                                     \
+    }                                                                                                             \
+  } while (0)
+
+  // ---- codebook loads of every piece, then the ring's loads: all out before anything is waited for ----
+  constexpr int NE = (BITS == 4) ? 4 : 9;
+  float ev[NT][NE];
+  if constexpr (!(ABL & 4)) {
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+      const int pN = SQLLM_PC(p, N), pcol0 = SQLLM_PC(p, col0);
+      const float* plut = SQLLM_PC(p, lut);
+      if constexpr (BITS == 4) {
+        // wave w stages column pair w & 1, entries [(w >> 1) * 4, + 4); lane >> 5 picks the even / odd column
+        int c = pcol0 + 4 * i16 + 2 * (wave & 1) + (lane >> 5);
+        if (c > pN - 1) c = pN - 1;
+        const f32x4 t = *SQLLM_GPTR(f32x4, plut + (size_t)c * 16 + (wave >> 1) * 4);
+        ev[p][0] = t.x; ev[p][1] = t.y; ev[p][2] = t.z; ev[p][3] = t.w;
+      } else {
+        // thread = (slot i16, lane column grp, second index = wave): the 8 entries of its column + entry `wave`
+        int c = pcol0 + 4 * i16 + grp;
+        if (c > pN - 1) c = pN - 1;
+        const float* src = plut + (size_t)c * 8;
+        const f32x4 ta = *SQLLM_GPTR(f32x4, src), tb4 = *SQLLM_GPTR(f32x4, src + 4);
+        ev[p][0] = ta.x; ev[p][1] = ta.y; ev[p][2] = ta.z; ev[p][3] = ta.w;
+        ev[p][4] = tb4.x; ev[p][5] = tb4.y; ev[p][6] = tb4.z; ev[p][7] = tb4.w;
+        ev[p][NE - 1] = *SQLLM_GPTR(float, src + wave);
+      }
+    }
+  }
+  // slabs [piece][wave][64] behind the tables: zero (a wave that never visits a piece leaves its slab alone)
+  float* slabs = reinterpret_cast<float*>(lds + NT * C::kTableBytes);
+  for (int i = tid; i < NT * WAVES * kTileN; i += WAVES * 64) slabs[i] = 0.f;
+#pragma unroll
+  for (int r = 0; r < RING; ++r) SQLLM_ISSUE(r);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- stage the tables (same layouts as dense_role, one table per piece) ----
+  if constexpr (!(ABL & 4)) {
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+      if constexpr (BITS == 4) {
+        float* dst = reinterpret_cast<float*>(lds + p * C::kTableBytes + (wave & 1) * 4096 + (wave >> 1) * 4 * 256) + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i * 64] = ev[p][i];
+      } else {
+        char* dst = lds + p * C::kTableBytes + grp * 8192 + wave * 8 * 128 + i16 * 8;
+#pragma unroll
+        for (int i0 = 0; i0 < 8; ++i0) *reinterpret_cast<f32x2*>(dst + i0 * 128) = f32x2{ev[p][i0], ev[p][NE - 1]};
+      }
+    }
+  }
+  __syncthreads();
+#ifdef SQLLM_ABLATION_BUILD
+  if (tl && tid == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  // ---- decode ----
+  f32x2 acc[4];  // 4-bit: [0], [1] = the two column pairs; 3-bit: per column (even k, odd k)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f32x2{0.f, 0.f};
+  const uint32_t lane_off = 4 * (i16 + 16 * (grp & 1));
+  int cur_p = d_p;  // piece the accumulators belong to
+
+  // park this wave's sums of piece P (fold the 4 lane rows first), clear the accumulators
+#define SQLLM_FLUSH(P)                                                                                          \
+  do {                                                                                                          \
+    float col_[4];                                                                                              \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                          \
+      float a_;                                                                                                 \
+      if constexpr (BITS == 4) a_ = (j_ & 1) ? acc[j_ >> 1].y : acc[j_ >> 1].x;                                 \
+      else a_ = acc[j_].x + acc[j_].y;                                                                          \
+      a_ += __shfl_xor(a_, 16, 64);                                                                             \
+      a_ += __shfl_xor(a_, 32, 64);                                                                             \
+      col_[j_] = a_;                                                                                            \
+    }                                                                                                           \
+    if (grp == 0)                                                                                               \
+      *reinterpret_cast<f32x4*>(slabs + ((P) * WAVES + wave) * kTileN + 4 * i16) = f32x4{col_[0], col_[1], col_[2], col_[3]}; \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) acc[j_] = f32x2{0.f, 0.f};                                 \
+  } while (0)
+
+#define SQLLM_DECODE(WS, X, XL)                                                                                 \
+  do {                                                                                                          \
+    if (d_u < u_end) {                                                                                          \
+      if (d_p != cur_p) {                                                                                       \
+        SQLLM_FLUSH(cur_p);                                                                                     \
+        cur_p = d_p;                                                                                            \
+      }                                                                                                         \
+      if constexpr (BITS == 4) {                                                                                \
+        f32x2 a2_[2] = {acc[0], acc[1]};                                                                        \
+        step4_stream<XL, ABL>(WS[0], X[0], lane_off, 0x20202020u * (uint32_t)cur_p, a2_);                       \
+        acc[0] = a2_[0];                                                                                        \
+        acc[1] = a2_[1];                                                                                        \
+      } else {                                                                                                  \
+        uint32_t tb_[4];                                                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) tb_[j_] = (uint32_t)cur_p * C::kTableBytes + j_ * 8192 + 8 * i16; \
+        step3_pair(WS, X[0], X[NX - 1], true, tb_, acc);                                                        \
+      }                                                                                                         \
+    }                                                                                                           \
+    d_u += WAVES;                                                                                               \
+    d_rg += WAVES;                                                                                              \
+    while (d_rg >= S) { d_rg -= S; ++d_p; }                                                                     \
+  } while (0)
+
+  while (d_u < u_end) {
+#pragma unroll
+    for (int r = 0; r < RING; ++r) {
+      SQLLM_DECODE(w[r][0], xs[r], 0);
+      if constexpr (SPS == 2) SQLLM_DECODE(w[r][SPS - 1], xs[r], 8);
+      SQLLM_ISSUE(r);  // refill the slot
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#ifdef SQLLM_ABLATION_BUILD
+  if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
+  if (tl && lane == 0 && wave < 4) tl[4 + wave] = __builtin_amdgcn_s_memrealtime();
+#endif
+  if constexpr (ABL & 8) {
+    if (acc[0].x + acc[0].y + acc[1].x + acc[1].y + acc[2].x + acc[3].y == 12345.678f) p0_y[0] = 1.f;
+    return;
+  }
+  if (cur_p < NT) SQLLM_FLUSH(cur_p);
+  __syncthreads();
+
+  // ---- wave p sums piece p's slabs: one atomic per column ----
+  if (wave < np && wave < NT) {
+    float sum = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < WAVES; ++wv) sum += slabs[(wave * WAVES + wv) * kTileN + lane];
+    float* y = SQLLM_PC(wave, y);
+    const int N = SQLLM_PC(wave, N), col0 = SQLLM_PC(wave, col0);
+    if (col0 + lane < N) acc_add(y + col0 + lane, sum);
+  }
+#ifdef SQLLM_ABLATION_BUILD
+  if (tl && tid == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
+#endif
+#undef SQLLM_ISSUE
+#undef SQLLM_FLUSH
+#undef SQLLM_DECODE
+#undef SQLLM_PC
+}
+
+template <int BITS, int ABL>
+__global__ void __launch_bounds__(kWaves * 64, StreamCfg<BITS>::kWgPerCu * 2)
+sqllm_stream_matvec(const StreamArgs sa_in, const GroupArgs ga) {
+  constexpr int T = kWaves * 64;
+  __shared__ __attribute__((aligned(16))) char lds[stream_lds_bytes(BITS)];
+  // the whole dense descriptor in ONE round of scalar loads (see sqllm_fused_matvec)
+  const StreamArgs sa = sa_in;
+  asm volatile("" ::"s"(sa.x), "s"(sa.K), "s"(sa.units_total), "s"(sa.steps_per_tile), "s"(sa.steps_per_wg), "s"(sa.total_steps),
+               "s"(sa.dense_block0), "s"(sa.n_seg), "s"(sa.seg[0].q), "s"(sa.seg[0].y), "s"(sa.seg[0].lut), "s"(sa.seg[0].N),
+               "s"(sa.seg[1].q), "s"(sa.seg[1].y), "s"(sa.seg[1].lut), "s"(sa.seg[1].N), "s"(sa.seg[1].tile0), "s"(sa.seg[2].q),
+               "s"(sa.seg[2].y), "s"(sa.seg[2].lut), "s"(sa.seg[2].N), "s"(sa.seg[2].tile0), "s"(sa.seg[3].q), "s"(sa.seg[3].y),
+               "s"(sa.seg[3].lut), "s"(sa.seg[3].N), "s"(sa.seg[3].tile0));
+  __builtin_amdgcn_sched_barrier(0);
+  const int bid = blockIdx.x;
+  if (bid >= sa.dense_block0) {
+    stream_dense<BITS, ABL>(sa, bid - sa.dense_block0, lds);
+    return;
+  }
+  // sparse roles of the launch's ops: [CSR chunks | top-X slabs] per op, op after op
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxSegments; ++i)
+    if (i < ga.n_seg && bid >= ga.block0[i]) s = i;
+  s = __builtin_amdgcn_readfirstlane(s);
+  const Segment sg = ga.seg[s];
+  asm volatile("" ::SQLLM_SEG_OPERANDS(sg));
+  __builtin_amdgcn_sched_barrier(0);
+  const KernelGeom& gm = sg.gm;
+  const int sp = bid - ga.block0[s];
+  const float* x = static_cast<const float*>(sa.x);
+  float* fl = reinterpret_cast<float*>(lds);
+  if (sp < gm.csr_blocks) {
+    csr_role<T, 1, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, 0, 1, sp, fl, nullptr, gm.sparse_last >> 1);
+  } else if (sp < gm.csr_blocks + gm.topx_blocks) {
+    topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, 0, 1, sp - gm.csr_blocks, fl);
+  }
+}
+
+template <int BITS, int ABL>
+static hipError_t launch_stream_inst(const StreamArgs& sa, const GroupArgs& ga, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+  dim3 grid(sa.dense_block0 + sa.n_dense);
+  auto kern = sqllm_stream_matvec<BITS, ABL>;
+  if (e0 || e1) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, e0, e1, 0, sa, ga);
+  else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, sa, ga);
+  return hipGetLastError();
+}
+
+hipError_t launch_stream(int bits, const StreamArgs& sa, const GroupArgs& ga, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
+                         int ablate) {
+#ifdef SQLLM_ABLATION_BUILD
+  if (bits == 4) {
+    switch (ablate) {
+      case 2: return launch_stream_inst<4, 2>(sa, ga, stream, e0, e1);
+      case 4: return launch_stream_inst<4, 4>(sa, ga, stream, e0, e1);
+      case 8: return launch_stream_inst<4, 8>(sa, ga, stream, e0, e1);
+      default: break;
+    }
+  }
+#else
+  (void)ablate;
+#endif
+  return bits == 4 ? launch_stream_inst<4, 0>(sa, ga, stream, e0, e1) : launch_stream_inst<3, 0>(sa, ga, stream, e0, e1);
+}
+
+}  // namespace sqllm

@@ -5,8 +5,8 @@ Every dense workgroup stamps the 100 MHz real-time clock at entry, after the cod
 the end of its decode loop and after its atomics; this prints the distribution of those stamps
 relative to the first workgroup's entry, next to the kernel's own duration.
 
-    SQLLM_ABLATION=1 python -m squeezellm_amd.build --force
-    python tools/timeline.py --shape 4096x4096 --bits 4 [--group 3]
+    python -m squeezellm_amd.build --ablation
+    SQLLM_LIB=squeezellm_amd/libsqllm_hip_ablation.so [SQLLM_OPTIONS=stream=0] python tools/timeline.py --shape 4096x4096 --bits 4 [--group 3]
 """
 import argparse
 import ctypes
@@ -41,7 +41,7 @@ def main():
     ys = [torch.zeros(N, device=dev) for _ in layers]
     seq = decode.OpSequence(layers, [x] * len(layers), ys, fuse_shared_input=a.group > 1)
     plan = _lib.plan_query(a.bits, K, N, nnz=0 if not a.sparse else layers[0]["vals"].numel(), topX=a.topx)
-    wgs = a.group * ((plan["grid_x"] + 7) // 8 * 8)
+    wgs = max(4096, a.group * ((plan["grid_x"] + 7) // 8 * 8))  # (the streaming kernel plans its own grid: be generous)
     buf = torch.zeros((len(seq.groups), wgs, 8), dtype=torch.int64, device=dev)
     seq.launch()  # warm (no probe)
     torch.cuda.synchronize()
