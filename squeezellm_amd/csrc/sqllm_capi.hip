@@ -242,8 +242,20 @@ bool takes_stream_path(const sqllm_op* ops, int n) {
   const int v = knobs().stream.load(std::memory_order_relaxed);
   if (v == 0) return false;
   if (v < 0) return false;  // default: off until it beats the fused kernel on the box it is measured on
-  for (int i = 0; i < n; ++i)
+  const int kK = ops[0].bits == 4 ? 8 : 32;
+  const uint32_t S = (uint32_t)((ops[0].K / kK + 3) / 4);
+  uint64_t tiles = 0;
+  for (int i = 0; i < n; ++i) {
     if (ops[i].batch > 1) return false;
+    // dead lanes / steps are pushed out of range by adding 2^31 to their offsets: operands stay below that
+    if ((uint64_t)ops[i].K / 32u * (uint64_t)ops[i].bits * (uint64_t)ops[i].N * 4u >= (1ull << 31)) return false;
+    if ((uint64_t)ops[i].K * 4u >= (1ull << 31)) return false;
+    tiles += (uint64_t)(ops[i].N + sqllm::kTileN - 1) / sqllm::kTileN;
+  }
+  // tile of a step by multiplication with m = ceil(2^32 / S): exact while step * (m * S - 2^32) < 2^32
+  const uint64_t m = ((1ull << 32) + S - 1) / S;
+  if (m >= (1ull << 32)) return false;  // S == 1: every step is a tile, no division needed -- rare, use the fused kernel
+  if (tiles * S * (m * S - (1ull << 32)) >= (1ull << 32)) return false;
   return true;
 }
 
@@ -256,12 +268,17 @@ void make_plan_stream(const sqllm_op* ops, int n, int sparse_blocks, sqllm::Stre
   const int bits = ops[0].bits;
   const int kK = bits == 4 ? 8 : 32;
   const int pieces = bits == 4 ? sqllm::kStreamPieces4 : sqllm::kStreamPieces3;
-  const int wg_per_cu = bits == 4 ? 3 : 2;
+#ifdef SQLLM_STREAM_WGCU
+  const int wg_per_cu = SQLLM_STREAM_WGCU;
+#else
+  const int wg_per_cu = bits == 4 ? 4 : 2;
+#endif
   memset(sa, 0, sizeof(*sa));
   sa->x = static_cast<const float*>(ops[0].vec);
   sa->K = ops[0].K;
   sa->units_total = ops[0].K / kK;
   sa->steps_per_tile = (sa->units_total + 3) / 4;
+  sa->s_magic = (uint32_t)(((1ull << 32) + sa->steps_per_tile - 1) / sa->steps_per_tile);
   sa->n_seg = n;
   int tiles = 0;
   for (int i = 0; i < sqllm::kMaxSegments; ++i) {
@@ -327,6 +344,13 @@ const char* sqllm_error_string(int code) {
 #ifdef SQLLM_ABLATION_BUILD
 // measurement build only (not in the header): device buffer of 8 x u64 per workgroup of the next launches
 void sqllm_debug_set_timeline(void* buf) { knobs().timeline.store(buf); }
+// measurement build only: the streaming kernel's plan for a group of ops -> {takes_stream, n_dense, steps_per_wg, steps_per_tile, total_steps}
+void sqllm_debug_stream_plan(const sqllm_op* ops, int n, int sparse_blocks, int* out) {
+  sqllm::StreamArgs sa;
+  out[0] = takes_stream_path(ops, n) ? 1 : 0;
+  make_plan_stream(ops, n, sparse_blocks, &sa);
+  out[1] = sa.n_dense; out[2] = sa.steps_per_wg; out[3] = sa.steps_per_tile; out[4] = sa.total_steps;
+}
 #endif
 
 int sqllm_set_option(const char* name, int value) {

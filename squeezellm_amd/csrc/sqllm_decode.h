@@ -231,6 +231,14 @@ __device__ __forceinline__ void step4_half(const u32x4& slot, const float (&xslo
   float xv[BT];
 #pragma unroll
   for (int b = 0; b < BT; ++b) xv[b] = valid ? xslot[b] : 0.f;
+  if constexpr (ABL & 2) {  // measurement: pure stream, no decode (the whole-stage step4 had this; the half-stage one did not)
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      acc[0][b].x += __builtin_bit_cast(float, t[0] ^ t[1]) * xv[b];
+      acc[1][b].x += __builtin_bit_cast(float, t[2] ^ t[3]) * xv[b];
+    }
+    return;
+  }
 #pragma unroll
   for (int jp = 0; jp < 2; ++jp) {
     f32x2 vp[8];
@@ -433,19 +441,37 @@ __device__ __forceinline__ void step3_pair(const u32x4 (&slot)[3], float xslot0,
 // workgroup here: measured +4.5 us per launch) and no launch-wide counter (a last-arriver that
 // must then touch all N columns measured +4-11 us per launch).
 //
-// Contributions are clamped to +-2^17 (twice the largest finite fp16) so that the at most 511 of
+// Contributions are clamped to +-2^17 (twice the largest finite fp16) so that the at most 127 of
 // them a column can receive stay inside the 55-bit field; sums beyond that are not finite in
 // fp16 anyway.  Rounding: 2^-28 absolute per contribution, far below one fp16 ulp of any normal
 // fp16 result.
+//
+// Non-finite values (round 3).  The reference's fp32 atomics carry NaN / Inf through to the output
+// (squeezellm/quant.py:214-223: zeros, op, cast); an integer sum cannot, so the word's two top bits
+// are STICKY FLAGS, set with an atomic OR by a contributor whose partial sum is not finite BEFORE
+// its counted add (atomics on one address are totally ordered, so whoever completes the count sees
+// every flag): bit 63 = a NaN was contributed, bit 62 = an infinity was (it also contributes its
+// clamped +-2^17, so the sign of the sum tells +inf from -inf, and a sum of zero -- infinities of
+// both signs -- is NaN, as inf - inf is).  The count keeps bits 55-61 (at most 127 contributions).
+// (Only the wide-span CSR fallback adds values uncounted; while such a word is transiently negative an
+// OR may be lost -- a NaN is then reported as a finite number, as before round 3.)
 // ------------------------------------------------------------------------------------------------
 typedef unsigned long long u64;
 constexpr int kFixShift = 28;
 constexpr int kCountShift = 55;
 constexpr u64 kCountUnit = 1ull << kCountShift;
+constexpr u64 kNanFlag = 1ull << 63, kInfFlag = 1ull << 62, kFlagMask = kNanFlag | kInfFlag;
 
 __device__ __forceinline__ u64 to_fixed(float v) {
-  v = __builtin_fminf(__builtin_fmaxf(v, -131072.f), 131072.f);  // also maps NaN to a bound
+  v = (v != v) ? 0.f : __builtin_fminf(__builtin_fmaxf(v, -131072.f), 131072.f);  // (a NaN rides in the flag, not in the sum)
   return (u64)(long long)__builtin_rintf(v * (float)(1 << kFixShift));
+}
+
+// set the word's sticky flag if `v` is not finite (call before the add that deposits v)
+__device__ __forceinline__ void flag_nonfinite(u64* word, float v) {
+  if (!(__builtin_fabsf(v) <= 3.402823466e38f))
+    __hip_atomic_fetch_or(reinterpret_cast<__attribute__((address_space(1))) u64*>(reinterpret_cast<uintptr_t>(word)),
+                          (v != v) ? kNanFlag : kInfFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // CSR chunks (kCsrChunk consecutive non-zeros each) holding part of a row that spans [r0, r1)
@@ -457,10 +483,15 @@ __device__ __forceinline__ int csr_chunks_of_row(int r0, int r1) {
 // last of the `target` contributions.
 __device__ __forceinline__ void column_done(const Segment& sg, u64* word, u64 total, unsigned target,
                                             size_t at, int c) {
+  const u64 flags = total & kFlagMask;
+  total &= ~kFlagMask;
   const u64 count = (total + (kCountUnit >> 1)) >> kCountShift;  // S may be negative: round, do not truncate
   if ((unsigned)count != target) return;
   const long long sfix = (long long)(total - (count << kCountShift));
-  const float v = (float)sfix * (1.f / (float)(1 << kFixShift)) + (sg.bias ? sg.bias[c] : 0.f);
+  float v = (float)sfix * (1.f / (float)(1 << kFixShift));
+  if (flags & kNanFlag) v = __builtin_nanf("");
+  else if (flags & kInfFlag) v = sfix > 0 ? __builtin_inff() : sfix < 0 ? -__builtin_inff() : __builtin_nanf("");
+  v += sg.bias ? sg.bias[c] : 0.f;
   reinterpret_cast<_Float16*>(sg.out16)[at] = (_Float16)v;
   atomicExch(word, 0ull);  // result unused: a plain atomic store
 }
@@ -475,6 +506,7 @@ __device__ __forceinline__ void acc_add(float* p, float v) {
   __hip_atomic_fetch_add(SQLLM_GLOBAL(float, p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void acc_add(u64* p, float v) {
+  flag_nonfinite(p, v);
   __hip_atomic_fetch_add(SQLLM_GLOBAL(u64, p), to_fixed(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

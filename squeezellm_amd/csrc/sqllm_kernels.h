@@ -9,7 +9,8 @@
 // one of them does not compile.
 #ifndef SQLLM_ABLATION_BUILD
 #if defined(SQLLM_PAIR3) || defined(SQLLM_PAIR3_NOCONFLICT) || defined(SQLLM_MFMA_VAR) || defined(SQLLM_MFMA_FAKE) || \
-    defined(SQLLM_HALF_STAGES) || defined(SQLLM_WAVES)
+    defined(SQLLM_HALF_STAGES) || defined(SQLLM_WAVES) || defined(SQLLM_STREAM_RING) || defined(SQLLM_STREAM_WGCU) || \
+    defined(SQLLM_STREAM_PRO)
 #error "kernel variant switches need -DSQLLM_ABLATION_BUILD (python -m squeezellm_amd.build --ablation)"
 #endif
 #endif
@@ -28,7 +29,7 @@ constexpr int kTopxRows = 128;     // k's per top-X slab
 constexpr int kTopxLds = 1024;     // topX up to which slab sums are kept in LDS
 constexpr int kMaxBatchTile = 8;   // batch rows handled per weight pass
 constexpr int kMaxSlices = 120;    // K slices per column tile
-constexpr int kMaxContrib = 511;   // fused linear: contributions one column may receive (9-bit count)
+constexpr int kMaxContrib = 127;   // fused linear: contributions one column may receive (7-bit count under the two non-finite flags)
 
 // LDS floats of one kernel instantiation: max over roles of
 //   dense: codebooks 4 column sub-tables * lut_entries * 32 slots (2 copies of 16 lanes) PLUS the
@@ -99,7 +100,7 @@ struct LaunchArgs {
 };
 
 // ---- streaming batch-1 kernel (sqllm_stream.hip) ----
-constexpr int kStreamPieces4 = 3;  // 64-column tiles one workgroup's range may touch (codebook tables resident at once), 4-bit
+constexpr int kStreamPieces4 = 2;  // 64-column tiles one workgroup's range may touch (codebook tables resident at once), 4-bit
 constexpr int kStreamPieces3 = 2;  // ... 3-bit (32 KiB pair tables)
 
 struct StreamSeg {  // one op of the launch, dense term only
@@ -122,6 +123,7 @@ struct StreamArgs {
   int dense_block0;    // first dense workgroup id (the sparse-role workgroups come first)
   int n_dense;         // dense workgroups
   int n_seg;
+  uint32_t s_magic;    // ceil(2^32 / steps_per_tile): tile of a step = mulhi(step, s_magic)
   StreamSeg seg[kMaxSegments];
   unsigned long long* probe;  // measurement builds: 8 timestamps per workgroup (tools/timeline.py); null otherwise
 };

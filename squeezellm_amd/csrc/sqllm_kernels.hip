@@ -137,6 +137,7 @@ __device__ __forceinline__ void dense_epilogue(const f32x2 (&acc)[2][BT], float*
         if (fold_topx) sum += topx_sum[b * kTileN + lane];
         if (lin) {
           const u64 mine = kCountUnit + to_fixed(sum);
+          flag_nonfinite(reinterpret_cast<u64*>(y) + at, sum);
           total[b] = atomicAdd(reinterpret_cast<u64*>(y) + at, mine) + mine;
         } else {
           atomicAdd(y + at, sum);

@@ -254,6 +254,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
           const int r0 = srows[i], r1 = srows[i + 1];
           if ((r0 > e0 ? r0 : e0) < (r1 < e1 ? r1 : e1)) {
             const u64 mine = kCountUnit + to_fixed(sum);
+            flag_nonfinite(y + at, sum);
             const unsigned target = (unsigned)lin->gm.k_slices + (unsigned)csr_chunks_of_row(r0, r1);
             column_done(*lin, y + at, atomicAdd(y + at, mine) + mine, target, at, c_lo + i);
           }

@@ -37,12 +37,23 @@
 
 namespace sqllm {
 
+// measurement switches (measurement builds only, see sqllm_kernels.h); production values:
+#ifndef SQLLM_STREAM_RING
+#define SQLLM_STREAM_RING 2
+#endif
+#ifndef SQLLM_STREAM_WGCU
+#define SQLLM_STREAM_WGCU 4
+#endif
+#ifndef SQLLM_STREAM_PRO
+#define SQLLM_STREAM_PRO 1  // ring slots requested BEFORE the codebook barrier (the rest right after it)
+#endif
+
 template <int BITS> struct StreamCfg;
 template <> struct StreamCfg<4> {
   static constexpr int kTableBytes = 8192;  // 2 column pairs x 16 entries x 256 B (two copies of 16 column groups)
   static constexpr int kPieces = kStreamPieces4;
-  static constexpr int kRing = 2;           // ring slots; a slot = TWO steps sharing one x register
-  static constexpr int kWgPerCu = 3;        // 80 VGPRs (the ring + the piece terms do not fit 64 without spills)
+  static constexpr int kRing = SQLLM_STREAM_RING;  // ring slots; a slot = TWO steps sharing one x register
+  static constexpr int kWgPerCu = SQLLM_STREAM_WGCU;  // 4: 64 VGPRs (ring of 2), 2: 128
 };
 template <> struct StreamCfg<3> {
   static constexpr int kTableBytes = 32768;  // 4 lane columns x 64 pair entries x 128 B
@@ -69,12 +80,33 @@ __device__ __forceinline__ float load_b32(rsrc_t r, uint32_t voff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
 }
 
-// 4-bit step with a table selector: `tmask` = (piece << 5) in every byte, OR-ed into the nibble bytes
-// by the same v_and_or that masks them, so that byte 1 of a lookup address is nibble + 32 * piece and
-// the address lands in the piece's 8 KiB table.  One column PAIR at a time (16 live lookups).
-template <int XL, int ABL>
-__device__ __forceinline__ void step4_stream(const u32x4& slot, float xv, uint32_t lane_off, uint32_t tmask,
-                                             f32x2 (&acc)[2]) {
+// Packed FMAs of one column pair against 8 consecutive x values.  The x values are broadcast (DPP) into the two
+// halves of FOUR register pairs and each packed FMA picks its half through op_sel: with `f32x2{x, x}` built from a
+// single register the instruction still names an aligned register PAIR whose other half is undefined -- and the
+// register allocator is free to put the destination of a load that is still in flight there, which costs a
+// vmcnt(0) in the middle of the decode (seen in the first version of this kernel).
+template <int XL>
+__device__ __forceinline__ void fma_pair_xp(const f32x2 (&vp)[8], float xv, f32x2& acc) {
+  const f32x2 x01 = {row_bcast<XL + 0>(xv), row_bcast<XL + 1>(xv)}, x23 = {row_bcast<XL + 2>(xv), row_bcast<XL + 3>(xv)};
+  const f32x2 x45 = {row_bcast<XL + 4>(xv), row_bcast<XL + 5>(xv)}, x67 = {row_bcast<XL + 6>(xv), row_bcast<XL + 7>(xv)};
+  f32x2 a = acc;
+  // (written as instructions: the compiler turns `splat(pair.x)` back into a fresh single-register operand)
+#define SQLLM_PKFMA_LO(V, X) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a) : "v"(V), "v"(X))
+#define SQLLM_PKFMA_HI(V, X) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a) : "v"(V), "v"(X))
+  SQLLM_PKFMA_LO(vp[0], x01); SQLLM_PKFMA_HI(vp[1], x01);
+  SQLLM_PKFMA_LO(vp[2], x23); SQLLM_PKFMA_HI(vp[3], x23);
+  SQLLM_PKFMA_LO(vp[4], x45); SQLLM_PKFMA_HI(vp[5], x45);
+  SQLLM_PKFMA_LO(vp[6], x67); SQLLM_PKFMA_HI(vp[7], x67);
+#undef SQLLM_PKFMA_LO
+#undef SQLLM_PKFMA_HI
+  acc = a;
+}
+
+// 4-bit step, lookups in the table of piece P (a compile-time constant: the table base rides in the
+// ds_read immediates; the decode loop holds one instance per piece and branches on the wave-uniform piece).
+// One column PAIR at a time (16 live lookups).
+template <int XL, int P, int ABL>
+__device__ __forceinline__ void step4_stream(const u32x4& slot, float xv, uint32_t lane_off, f32x2 (&acc)[2]) {
   uint32_t t[4] = {slot.x, slot.y, slot.z, slot.w};
   SQLLM_PIN4(t[0], t[1], t[2], t[3]);
   if constexpr (ABL & 2) {
@@ -82,16 +114,15 @@ __device__ __forceinline__ void step4_stream(const u32x4& slot, float xv, uint32
     acc[1].x += __builtin_bit_cast(float, t[2] ^ t[3]) * xv;
     return;
   }
-  const float xa[1] = {xv};
 #pragma unroll
   for (int jp = 0; jp < 2; ++jp) {
     f32x2 vp[8];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int j = 2 * jp + h;
-      const uint32_t lo = (t[j] & 0x0F0F0F0Fu) | tmask;
-      const uint32_t hi = ((t[j] >> 4) & 0x0F0F0F0Fu) | tmask;
-      const int off = jp * 4096 + h * 128;
+      const uint32_t lo = t[j] & 0x0F0F0F0Fu;
+      const uint32_t hi = (t[j] >> 4) & 0x0F0F0F0Fu;
+      const int off = P * StreamCfg<4>::kTableBytes + jp * 4096 + h * 128;
       float e[8];
       e[0] = lookup<ABL>(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0400u) + off);
       e[1] = lookup<ABL>(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0400u) + off);
@@ -106,28 +137,26 @@ __device__ __forceinline__ void step4_stream(const u32x4& slot, float xv, uint32
         if (h) vp[i].y = e[i]; else vp[i].x = e[i];
       }
     }
-    f32x2 a1[1] = {acc[jp]};
-    fma_pair<1, XL>(vp, xa, a1);
-    acc[jp] = a1[0];
+    fma_pair_xp<XL>(vp, xv, acc[jp]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// One piece of a workgroup's range = a 64-column tile of one op of the launch: the op's operands and the tile's
-// first column (all wave-uniform).
-template <int BITS>
-__device__ __forceinline__ void piece_terms(const StreamArgs& sa, int T, int i16, int grp, const char*& q, float*& y,
-                                            const float*& lut, int& N, int& col0) {
+// Which op of the launch owns global tile T, and the op's operands (all wave-uniform: compares + selects).
+struct PieceOps { const char* q; float* y; const float* lut; int N, col0; };
+__device__ __forceinline__ PieceOps piece_ops(const StreamArgs& sa, int T) {
   int s = 0;
   if (sa.n_seg > 1 && T >= sa.seg[1].tile0) s = 1;
   if (sa.n_seg > 2 && T >= sa.seg[2].tile0) s = 2;
   if (sa.n_seg > 3 && T >= sa.seg[3].tile0) s = 3;
-  q = reinterpret_cast<const char*>(s == 0 ? sa.seg[0].q : s == 1 ? sa.seg[1].q : s == 2 ? sa.seg[2].q : sa.seg[3].q);
-  y = s == 0 ? sa.seg[0].y : s == 1 ? sa.seg[1].y : s == 2 ? sa.seg[2].y : sa.seg[3].y;
-  lut = s == 0 ? sa.seg[0].lut : s == 1 ? sa.seg[1].lut : s == 2 ? sa.seg[2].lut : sa.seg[3].lut;
-  N = s == 0 ? sa.seg[0].N : s == 1 ? sa.seg[1].N : s == 2 ? sa.seg[2].N : sa.seg[3].N;
+  PieceOps o;
+  o.q = reinterpret_cast<const char*>(s == 0 ? sa.seg[0].q : s == 1 ? sa.seg[1].q : s == 2 ? sa.seg[2].q : sa.seg[3].q);
+  o.y = s == 0 ? sa.seg[0].y : s == 1 ? sa.seg[1].y : s == 2 ? sa.seg[2].y : sa.seg[3].y;
+  o.lut = s == 0 ? sa.seg[0].lut : s == 1 ? sa.seg[1].lut : s == 2 ? sa.seg[2].lut : sa.seg[3].lut;
+  o.N = s == 0 ? sa.seg[0].N : s == 1 ? sa.seg[1].N : s == 2 ? sa.seg[2].N : sa.seg[3].N;
   const int tile0 = s == 0 ? 0 : s == 1 ? sa.seg[1].tile0 : s == 2 ? sa.seg[2].tile0 : sa.seg[3].tile0;
-  col0 = (T - tile0) * kTileN;
+  o.col0 = (T - tile0) * kTileN;
+  return o;
 }
 
 // this lane's byte offset inside a step of a piece: 4-bit: its row of the step's 4 + its 16 bytes of the row; 3-bit: its 16 bytes
@@ -138,7 +167,7 @@ __device__ __forceinline__ uint32_t lane_offset_in_step(int N, int col0, int i16
   return (BITS == 4 ? (uint32_t)grp * (4u * (uint32_t)N) : 0u) + 16u * (uint32_t)cidx;
 }
 
-#define SQLLM_GPTR(T, p) reinterpret_cast<const __attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p))
+constexpr uint32_t kDeadOffset = 0x80000000u;  // added to a buffer offset: out of every descriptor's range (operands < 2 GiB)
 
 template <int BITS, int ABL>
 __device__ __forceinline__ void stream_dense(const StreamArgs& sa, int bid, char* lds) {
@@ -151,133 +180,120 @@ __device__ __forceinline__ void stream_dense(const StreamArgs& sa, int bid, char
   constexpr int SPS = (BITS == 4) ? 2 : 1;  // steps per ring slot
   constexpr int NX = (BITS == 4) ? 1 : 2;   // x registers per ring slot
   static_assert(WAVES == 8, "staging assigns table rows by wave");
-  static_assert(NT == 2 || NT == 3, "three named pieces");
+  static_assert(NT == 2, "two pieces: p0_* / p1_*");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, grp = lane >> 4;
 
-  // ---- this workgroup's range of steps, its pieces (all wave-uniform) ----
+  // ---- this workgroup's range of steps and its (one or two) pieces: all wave-uniform ----
   const int S = sa.steps_per_tile;
   const int u_beg = bid * sa.steps_per_wg;
   int u_end = u_beg + sa.steps_per_wg;
   if (u_end > sa.total_steps) u_end = sa.total_steps;
   if (u_beg >= u_end) return;
-  const int T0 = __builtin_amdgcn_readfirstlane((unsigned)u_beg / (unsigned)S);
-  const int T1 = __builtin_amdgcn_readfirstlane((unsigned)(u_end - 1) / (unsigned)S);
-  const int np = T1 - T0 + 1;      // <= NT (the host's plan guarantees it)
+  // tile of a step = step / S, by multiplication with ceil(2^32 / S) (exact for every step of the launch: the host checks)
+  const int T0 = (int)__umulhi((uint32_t)u_beg, sa.s_magic);
+  const int T1 = (int)__umulhi((uint32_t)(u_end - 1), sa.s_magic);
+  const bool two = T1 != T0;       // (the host's plan guarantees T1 <= T0 + 1)
   const int rg0 = u_beg - T0 * S;  // first step's position inside tile T0
-  const rsrc_t x_rsrc = make_rsrc(sa.x, 4u * (uint32_t)sa.K);
 #ifdef SQLLM_ABLATION_BUILD
   unsigned long long* tl = sa.probe ? sa.probe + 8ull * blockIdx.x : nullptr;
   if (tl && tid == 0) tl[0] = __builtin_amdgcn_s_memrealtime();
 #endif
+  const PieceOps o0 = piece_ops(sa, T0), o1 = piece_ops(sa, T1);
+  const uint32_t qbytes0 = (uint32_t)(sa.units_total * R) * 4u * (uint32_t)o0.N, qbytes1 = (uint32_t)(sa.units_total * R) * 4u * (uint32_t)o1.N;
+  const rsrc_t x_rsrc = make_rsrc(sa.x, 4u * (uint32_t)sa.K);
 
-  // Per-piece terms live in plain named scalars (p0_*, p1_*, p2_*), selected by compares: an array or a
-  // struct selected by the run-time piece index ends up as an indexed load from scratch memory.
-  // (pieces past the last one repeat it: staged twice, never decoded, never flushed)
-#define SQLLM_PIECE(I)                                                                                                  \
-  const char* p##I##_q; float* p##I##_y; const float* p##I##_lut; int p##I##_N, p##I##_col0;                              \
-  piece_terms<BITS>(sa, (T0 + I > T1 ? T1 : T0 + I), i16, grp, p##I##_q, p##I##_y, p##I##_lut, p##I##_N, p##I##_col0)
-  SQLLM_PIECE(0);
-  SQLLM_PIECE(1);
-  SQLLM_PIECE(2);  // (NT == 2: never selected)
-#undef SQLLM_PIECE
-#define SQLLM_PC(p, f) ((p) == 0 ? p0_##f : ((p) == 1 || NT < 3) ? p1_##f : p2_##f)
-
-  // ---- cursors: (piece, step inside the piece's tile, global step) of the next step to LOAD / to DECODE.
-  //      The waves interleave steps over the whole range: wave w takes u_beg + w, + WAVES, ...
-  //      The load cursor carries its piece's addressing terms along and re-selects them only when it
-  //      crosses into the next piece (scalar control flow without memory operations).
-  int l_p = 0, l_rg = rg0 + wave, l_u = u_beg + wave;
-  while (l_rg >= S) { l_rg -= S; ++l_p; }
-  int d_p = l_p, d_rg = l_rg, d_u = l_u;
-  const char* l_q = SQLLM_PC(l_p, q);
-  uint32_t l_rb = 4u * (uint32_t)SQLLM_PC(l_p, N);  // bytes per qweight row of the load cursor's piece
-  uint32_t l_vlane = lane_offset_in_step<BITS>(SQLLM_PC(l_p, N), SQLLM_PC(l_p, col0), i16, grp);
-
-  // ---- ring of loads ----
-  u32x4 w[RING][SPS][R];
-  float xs[RING][NX];
-  // Loads are unconditional (a load under a branch makes the compiler wait for everything in flight at the
-  // join).  A step past the end of the range ("dead": the ring runs ahead of the decode) reads 16 bytes per lane
-  // of vec instead -- always cache-resident, never decoded; its x comes back as zeros (out of the
-  // descriptor's range).  x: 4-bit: lane i of a 16-lane row holds x[8 * unit + (i & 7)], lanes 0-7 for the
-  // slot's first step, lanes 8-15 for its second; 3-bit: two registers, x[32 * unit + i] and x[32 * unit + 16 + i].
-  const char* dead_q = reinterpret_cast<const char*>(sa.x);
-#define SQLLM_ISSUE(r)                                                                                            \
-  do {                                                                                                            \
-    uint32_t xoff_[SPS];                                                                                          \
-    _Pragma("unroll") for (int s_ = 0; s_ < SPS; ++s_) {                                                          \
-      const bool live_ = l_u < u_end;                                                                             \
-      const char* base_ = live_ ? l_q : dead_q;                                                                   \
-      const uint32_t unit_ = 4u * (uint32_t)l_rg + (uint32_t)grp;                                                 \
-      uint32_t voff_;                                                                                             \
-      if constexpr (BITS == 4) {                                                                                  \
-        voff_ = l_vlane + (uint32_t)l_rg * (4u * l_rb);                                                           \
-      } else { /* a tile's last step may be ragged (K / 32 not a multiple of 4): such lanes re-read the last unit */ \
-        uint32_t uc_ = unit_;                                                                                     \
-        if (uc_ > (uint32_t)sa.units_total - 1u) uc_ = (uint32_t)sa.units_total - 1u;                             \
-        voff_ = l_vlane + uc_ * (3u * l_rb);                                                                      \
-      }                                                                                                           \
-      voff_ = live_ ? voff_ : 16u * (uint32_t)(i16 & 7);                                                          \
-      const uint32_t rb_ = live_ ? l_rb : 0u;                                                                     \
-      _Pragma("unroll") for (int rr_ = 0; rr_ < R; ++rr_)                                                         \
-        w[r][s_][rr_] = __builtin_nontemporal_load(SQLLM_GPTR(u32x4, base_ + (voff_ + (uint32_t)rr_ * rb_)));    \
-      xoff_[s_] = live_ ? 4u * ((uint32_t)F::kK * unit_) : 0xFFFFFF00u; /* (ragged lanes: past K, zeros) */       \
-      l_u += WAVES;                                                                                               \
-      l_rg += WAVES;                                                                                              \
-      if (l_rg >= S) {                                                                                            \
-        while (l_rg >= S) { l_rg -= S; ++l_p; }                                                                   \
-        const int lp_ = l_p < NT ? l_p : NT - 1;                                                                  \
-        l_q = SQLLM_PC(lp_, q);                                                                                   \
-        l_rb = 4u * (uint32_t)SQLLM_PC(lp_, N);                                                                   \
-        l_vlane = lane_offset_in_step<BITS>(SQLLM_PC(lp_, N), SQLLM_PC(lp_, col0), i16, grp);                     \
-      }                                                                                                           \
-    }                                                                                                             \
-    if constexpr (BITS == 4) {                                                                                    \
-      xs[r][0] = load_b32(x_rsrc, ((i16 & 8) ? xoff_[SPS - 1] : xoff_[0]) + 4u * (uint32_t)(i16 & 7));            \
-    } else {                                                                                                      \
-      xs[r][0] = load_b32(x_rsrc, xoff_[0] + 4u * (uint32_t)i16);                                                 \
-      xs[r][NX - 1] = load_b32(x_rsrc, xoff_[0] + 4u * (uint32_t)(i16 + 16));                                     \
-    }                                                                                                             \
-  } while (0)
-
-  // ---- codebook loads of every piece, then the ring's loads: all out before anything is waited for ----
+  // ---- codebook loads first (piece 1 only exists when the range crosses a tile boundary: otherwise its
+  //      loads are out of the descriptor's range -- no memory access -- and its table is never read) ----
   constexpr int NE = (BITS == 4) ? 4 : 9;
   float ev[NT][NE];
   if constexpr (!(ABL & 4)) {
 #pragma unroll
     for (int p = 0; p < NT; ++p) {
-      const int pN = SQLLM_PC(p, N), pcol0 = SQLLM_PC(p, col0);
-      const float* plut = SQLLM_PC(p, lut);
+      const PieceOps& o = p ? o1 : o0;
+      const rsrc_t lr = make_rsrc(o.lut, (uint32_t)o.N * (uint32_t)F::kLut * 4u);
+      const uint32_t dead = (p == 1 && !two) ? kDeadOffset : 0u;
       if constexpr (BITS == 4) {
         // wave w stages column pair w & 1, entries [(w >> 1) * 4, + 4); lane >> 5 picks the even / odd column
-        int c = pcol0 + 4 * i16 + 2 * (wave & 1) + (lane >> 5);
-        if (c > pN - 1) c = pN - 1;
-        const f32x4 t = *SQLLM_GPTR(f32x4, plut + (size_t)c * 16 + (wave >> 1) * 4);
+        int c = o.col0 + 4 * i16 + 2 * (wave & 1) + (lane >> 5);
+        if (c > o.N - 1) c = o.N - 1;
+        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr, (uint32_t)(c * 16 + (wave >> 1) * 4) * 4u + dead, 0, 0));
         ev[p][0] = t.x; ev[p][1] = t.y; ev[p][2] = t.z; ev[p][3] = t.w;
       } else {
         // thread = (slot i16, lane column grp, second index = wave): the 8 entries of its column + entry `wave`
-        int c = pcol0 + 4 * i16 + grp;
-        if (c > pN - 1) c = pN - 1;
-        const float* src = plut + (size_t)c * 8;
-        const f32x4 ta = *SQLLM_GPTR(f32x4, src), tb4 = *SQLLM_GPTR(f32x4, src + 4);
+        int c = o.col0 + 4 * i16 + grp;
+        if (c > o.N - 1) c = o.N - 1;
+        const uint32_t off = (uint32_t)c * 32u + dead;
+        const f32x4 ta = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr, off, 0, 0));
+        const f32x4 tb4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr, off + 16u, 0, 0));
         ev[p][0] = ta.x; ev[p][1] = ta.y; ev[p][2] = ta.z; ev[p][3] = ta.w;
         ev[p][4] = tb4.x; ev[p][5] = tb4.y; ev[p][6] = tb4.z; ev[p][7] = tb4.w;
-        ev[p][NE - 1] = *SQLLM_GPTR(float, src + wave);
+        ev[p][NE - 1] = load_b32(lr, off + 4u * (uint32_t)wave);
       }
     }
   }
-  // slabs [piece][wave][64] behind the tables: zero (a wave that never visits a piece leaves its slab alone)
-  float* slabs = reinterpret_cast<float*>(lds + NT * C::kTableBytes);
-  for (int i = tid; i < NT * WAVES * kTileN; i += WAVES * 64) slabs[i] = 0.f;
+
+  // ---- cursors: (piece, step inside the piece's tile, global step) of the next step to LOAD / to DECODE.
+  //      The waves interleave steps over the whole range: wave w takes u_beg + w, + WAVES, ...
+  //      The load cursor carries its piece's descriptor and this lane's offset along and re-derives them only
+  //      when it crosses into the next piece (scalar control flow, no memory operations).
+  int l_p = 0, l_rg = rg0 + wave, l_u = u_beg + wave;
+  while (l_rg >= S) { l_rg -= S; ++l_p; }
+  int d_p = l_p, d_rg = l_rg, d_u = l_u;
+  rsrc_t l_desc = l_p == 0 ? make_rsrc(o0.q, qbytes0) : make_rsrc(o1.q, qbytes1);
+  uint32_t l_rb = 4u * (uint32_t)(l_p == 0 ? o0.N : o1.N);  // bytes per qweight row of the load cursor's piece
+  uint32_t l_vlane = l_p == 0 ? lane_offset_in_step<BITS>(o0.N, o0.col0, i16, grp) : lane_offset_in_step<BITS>(o1.N, o1.col0, i16, grp);
+
+  // ---- ring of loads ----
+  // Loads are unconditional raw buffer loads (a load under a branch makes the compiler wait for everything in
+  // flight at the join).  A step past the end of the range ("dead": the ring runs ahead of the decode) gets
+  // kDeadOffset added to its offsets: out of the descriptors' range, zeros, no memory access -- as do lanes
+  // past a ragged end of K.  x: 4-bit: lane i of a 16-lane row holds x[8 * unit + (i & 7)], lanes 0-7 for the
+  // slot's first step, lanes 8-15 for its second; 3-bit: two registers, x[32 * unit + i] and x[32 * unit + 16 + i].
+  u32x4 w[RING][SPS][R];
+  float xs[RING][NX];
+  const uint32_t x_lane = (BITS == 4) ? 4u * (uint32_t)(8 * grp + (i16 & 7)) : 4u * (uint32_t)(32 * grp + i16);
+#define SQLLM_ISSUE(r)                                                                                            \
+  do {                                                                                                            \
+    uint32_t xs_[SPS];                                                                                            \
+    _Pragma("unroll") for (int s_ = 0; s_ < SPS; ++s_) {                                                          \
+      const uint32_t dead_ = l_u < u_end ? 0u : kDeadOffset;                                                      \
+      const uint32_t soff_ = (uint32_t)l_rg * (4u * (uint32_t)R * l_rb) + dead_; /* 4 units of R rows per step */ \
+      uint32_t voff_ = l_vlane + soff_;                                                                           \
+      if constexpr (BITS == 3) voff_ += (uint32_t)grp * 3u * l_rb; /* (4-bit: the lane's row is part of l_vlane) */ \
+      _Pragma("unroll") for (int rr_ = 0; rr_ < R; ++rr_) w[r][s_][rr_] = load_b128_nt(l_desc, voff_, (uint32_t)rr_ * l_rb); \
+      xs_[s_] = (uint32_t)l_rg * (16u * (uint32_t)F::kK) + dead_;                                                 \
+      l_u += WAVES;                                                                                               \
+      l_rg += WAVES;                                                                                              \
+      if (l_rg >= S) {                                                                                            \
+        while (l_rg >= S) { l_rg -= S; ++l_p; }                                                                   \
+        l_desc = l_p == 0 ? make_rsrc(o0.q, qbytes0) : make_rsrc(o1.q, qbytes1);                                  \
+        l_rb = 4u * (uint32_t)(l_p == 0 ? o0.N : o1.N);                                                           \
+        l_vlane = l_p == 0 ? lane_offset_in_step<BITS>(o0.N, o0.col0, i16, grp) : lane_offset_in_step<BITS>(o1.N, o1.col0, i16, grp); \
+      }                                                                                                           \
+    }                                                                                                             \
+    if constexpr (BITS == 4) {                                                                                    \
+      xs[r][0] = load_b32(x_rsrc, ((i16 & 8) ? xs_[SPS - 1] : xs_[0]) + x_lane);                                  \
+    } else {                                                                                                      \
+      xs[r][0] = load_b32(x_rsrc, xs_[0] + x_lane);                                                               \
+      xs[r][NX - 1] = load_b32(x_rsrc, xs_[0] + x_lane + 64u);                                                    \
+    }                                                                                                             \
+  } while (0)
+  // Only PRO slots go out before the barrier: a CU's memory pipe serves requests in order, and the barrier
+  // needs the codebook loads of the workgroup's LAST wave -- which sit behind every load the earlier waves
+  // have issued by then (with the whole ring of 4 slots in front: entry -> barrier 2.7-3.6 us).
+  constexpr int PRO = SQLLM_STREAM_PRO < RING ? SQLLM_STREAM_PRO : RING;
 #pragma unroll
-  for (int r = 0; r < RING; ++r) SQLLM_ISSUE(r);
+  for (int r = 0; r < PRO; ++r) SQLLM_ISSUE(r);
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- stage the tables (same layouts as dense_role, one table per piece) ----
+  // ---- stage the tables (same layouts as dense_role, one table per piece); slabs [piece][wave][64] behind
+  //      them start at zero (a wave that never visits a piece leaves its slab alone) ----
+  float* slabs = reinterpret_cast<float*>(lds + NT * C::kTableBytes);
+  for (int i = tid; i < NT * WAVES * kTileN; i += WAVES * 64) slabs[i] = 0.f;
   if constexpr (!(ABL & 4)) {
 #pragma unroll
     for (int p = 0; p < NT; ++p) {
@@ -293,6 +309,9 @@ __device__ __forceinline__ void stream_dense(const StreamArgs& sa, int bid, char
     }
   }
   __syncthreads();
+#pragma unroll
+  for (int r = PRO; r < RING; ++r) SQLLM_ISSUE(r);
+  __builtin_amdgcn_sched_barrier(0);
 #ifdef SQLLM_ABLATION_BUILD
   if (tl && tid == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -330,7 +349,8 @@ __device__ __forceinline__ void stream_dense(const StreamArgs& sa, int bid, char
       }                                                                                                         \
       if constexpr (BITS == 4) {                                                                                \
         f32x2 a2_[2] = {acc[0], acc[1]};                                                                        \
-        step4_stream<XL, ABL>(WS[0], X[0], lane_off, 0x20202020u * (uint32_t)cur_p, a2_);                       \
+        if (cur_p == 0) step4_stream<XL, 0, ABL>(WS[0], X[0], lane_off, a2_);                                   \
+        else step4_stream<XL, 1, ABL>(WS[0], X[0], lane_off, a2_);                                              \
         acc[0] = a2_[0];                                                                                        \
         acc[1] = a2_[1];                                                                                        \
       } else {                                                                                                  \
@@ -358,19 +378,19 @@ __device__ __forceinline__ void stream_dense(const StreamArgs& sa, int bid, char
   if (tl && lane == 0 && wave < 4) tl[4 + wave] = __builtin_amdgcn_s_memrealtime();
 #endif
   if constexpr (ABL & 8) {
-    if (acc[0].x + acc[0].y + acc[1].x + acc[1].y + acc[2].x + acc[3].y == 12345.678f) p0_y[0] = 1.f;
+    if (acc[0].x + acc[0].y + acc[1].x + acc[1].y + acc[2].x + acc[3].y == 12345.678f) o0.y[0] = 1.f;
     return;
   }
   if (cur_p < NT) SQLLM_FLUSH(cur_p);
   __syncthreads();
 
   // ---- wave p sums piece p's slabs: one atomic per column ----
-  if (wave < np && wave < NT) {
+  if (wave == 0 || (wave == 1 && two)) {
     float sum = 0.f;
 #pragma unroll
     for (int wv = 0; wv < WAVES; ++wv) sum += slabs[(wave * WAVES + wv) * kTileN + lane];
-    float* y = SQLLM_PC(wave, y);
-    const int N = SQLLM_PC(wave, N), col0 = SQLLM_PC(wave, col0);
+    float* y = wave == 0 ? o0.y : o1.y;
+    const int N = wave == 0 ? o0.N : o1.N, col0 = wave == 0 ? o0.col0 : o1.col0;
     if (col0 + lane < N) acc_add(y + col0 + lane, sum);
   }
 #ifdef SQLLM_ABLATION_BUILD
@@ -379,7 +399,6 @@ __device__ __forceinline__ void stream_dense(const StreamArgs& sa, int bid, char
 #undef SQLLM_ISSUE
 #undef SQLLM_FLUSH
 #undef SQLLM_DECODE
-#undef SQLLM_PC
 }
 
 template <int BITS, int ABL>
@@ -390,7 +409,7 @@ sqllm_stream_matvec(const StreamArgs sa_in, const GroupArgs ga) {
   // the whole dense descriptor in ONE round of scalar loads (see sqllm_fused_matvec)
   const StreamArgs sa = sa_in;
   asm volatile("" ::"s"(sa.x), "s"(sa.K), "s"(sa.units_total), "s"(sa.steps_per_tile), "s"(sa.steps_per_wg), "s"(sa.total_steps),
-               "s"(sa.dense_block0), "s"(sa.n_seg), "s"(sa.seg[0].q), "s"(sa.seg[0].y), "s"(sa.seg[0].lut), "s"(sa.seg[0].N),
+               "s"(sa.dense_block0), "s"(sa.n_seg), "s"(sa.s_magic), "s"(sa.seg[0].q), "s"(sa.seg[0].y), "s"(sa.seg[0].lut), "s"(sa.seg[0].N),
                "s"(sa.seg[1].q), "s"(sa.seg[1].y), "s"(sa.seg[1].lut), "s"(sa.seg[1].N), "s"(sa.seg[1].tile0), "s"(sa.seg[2].q),
                "s"(sa.seg[2].y), "s"(sa.seg[2].lut), "s"(sa.seg[2].N), "s"(sa.seg[2].tile0), "s"(sa.seg[3].q), "s"(sa.seg[3].y),
                "s"(sa.seg[3].lut), "s"(sa.seg[3].N), "s"(sa.seg[3].tile0));

@@ -156,6 +156,8 @@ class QuantLinearLUTFused(QuantLinearLUT):
         key = (self.rows.data_ptr(), self.vals.data_ptr(), self.vals.numel())
         if self.__dict__.get("_csr_ok") == key:
             return
+        if torch.cuda.is_current_stream_capturing():
+            return  # the check reads back from the device, which would invalidate the capture: deferred to the next eager call
         r = self.rows
         ok = r.numel() == self.outfeatures + 1 and bool((r[1:] >= r[:-1]).all()) and int(r[0]) == 0 and int(r[-1]) == self.vals.numel()
         if not ok:

@@ -22,6 +22,13 @@ identical sequence of collectives, so the schedule cannot deadlock.
 
 The exchange logic is backend-agnostic and is covered on CPU with gloo (tests/test_sharding_cpu.py)
 by injecting a CPU stage function; the product stage (`DecodeStage`) launches the HIP kernels.
+
+Second split (path 2): BY OUTPUT COLUMN inside a layer.  `qweight[:, n0:n1]`,
+`lookup_table[n0:n1]`, the CSR rows n0..n1 and the top-X rows whose column falls in the range
+partition by N with NO reduction: every rank computes its slice of `mul` and ONE all-gather of the
+slices (N * 4 bytes <= 88 KiB) rebuilds the vector (`shard_layer_columns`, `ColumnParallelOp`).  This
+is the split that shortens a single token's latency (every GPU streams 1 / W of every layer), at the
+price of one latency-bound collective per linear.
 """
 from __future__ import annotations
 
@@ -78,6 +85,77 @@ class RingPipeline:
             self.tick()
 
 
+def column_ranges(N: int, world_size: int, align: int = 64) -> List[Tuple[int, int]]:
+    """[n0, n1) of every rank: contiguous, multiples of `align` columns (the kernels' tile width; N % 4 == 0 is
+    what they require), as equal as that allows; trailing ranks may be empty when N is small."""
+    if N < 0 or world_size < 1 or align < 4 or align % 4:
+        raise ValueError("need N >= 0, world_size >= 1, align a positive multiple of 4")
+    blocks = -(-N // align)
+    out = []
+    for a, b in partition_layers(blocks, world_size):
+        out.append((min(a * align, N), min(b * align, N)))
+    return out
+
+
+def shard_layer_columns(layer: dict, rank: int, world_size: int, align: int = 64) -> dict:
+    """This rank's column slice of one quantised linear's operands (a dict as squeezellm_amd.synth / checkpoint
+    produce them): `qweight[:, n0:n1]`, `lookup_table[n0:n1]`, bias, the CSR rows n0..n1 re-based to start at 0,
+    and the top-X rows whose output column falls inside the range (indices re-based).  Pure tensor slicing: works
+    on CPU and GPU tensors alike; the result is a valid operand set for every operator of the library."""
+    n0, n1 = column_ranges(layer["N"], world_size, align)[rank]
+    out = dict(layer)
+    out["N"] = n1 - n0
+    out["col_range"] = (n0, n1)
+    out["qweight"] = layer["qweight"][:, n0:n1].contiguous()
+    out["lookup_table"] = layer["lookup_table"][n0:n1].contiguous()
+    if layer.get("bias") is not None:
+        out["bias"] = layer["bias"][n0:n1].contiguous()
+    if layer.get("vals") is not None:
+        rows = layer["rows"]
+        e0, e1 = int(rows[n0]), int(rows[n1])
+        out["rows"] = (rows[n0:n1 + 1] - e0).contiguous()
+        out["cols"] = layer["cols"][e0:e1].contiguous()
+        out["vals"] = layer["vals"][e0:e1].contiguous()
+    if layer.get("full_rows") is not None:
+        idx = layer["full_row_indices"]
+        keep = ((idx >= n0) & (idx < n1)).nonzero().flatten()
+        if keep.numel():
+            out["full_rows"] = layer["full_rows"][:, keep].contiguous()
+            out["full_row_indices"] = (idx[keep] - n0).to(idx.dtype).contiguous()
+        else:  # no top-X row lands in this range
+            out["full_rows"], out["full_row_indices"] = None, None
+    return out
+
+
+class ColumnParallelOp:
+    """One quantised linear split by output column over the ranks of a process group: `local_fn(x) -> y_slice`
+    computes this rank's columns (the HIP kernels on the sharded operands, or a test double), one all-gather
+    rebuilds the full `mul`.  Slices are padded to the widest one for the collective (ranges are equal up to
+    one 64-column block)."""
+
+    def __init__(self, local_fn: Callable[[torch.Tensor], torch.Tensor], N: int, *, rank: int, world_size: int, device,
+                 dtype=torch.float32, group=None, align: int = 64):
+        self.local_fn, self.N, self.rank, self.world, self.group = local_fn, N, rank, world_size, group
+        self.ranges = column_ranges(N, world_size, align)
+        self.width = max(b - a for a, b in self.ranges) if self.ranges else 0
+        self.buf = torch.zeros((world_size, max(self.width, 1)), device=device, dtype=dtype)
+        self.mine = torch.zeros(max(self.width, 1), device=device, dtype=dtype)
+        self._chunks = list(self.buf.unbind(0))
+        self._use_flat = hasattr(dist, "all_gather_into_tensor") and (dist.get_backend(group) != "gloo" if dist.is_initialized() else True)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        n0, n1 = self.ranges[self.rank]
+        if n1 > n0:
+            self.mine[: n1 - n0].copy_(self.local_fn(x).reshape(-1))
+        if self.world == 1:
+            self.buf[0].copy_(self.mine)
+        elif self._use_flat:
+            dist.all_gather_into_tensor(self.buf, self.mine, group=self.group)
+        else:
+            dist.all_gather(self._chunks, self.mine, group=self.group)
+        return torch.cat([self.buf[r, : b - a] for r, (a, b) in enumerate(self.ranges)])
+
+
 class DecodeStage:
     """This rank's slice of a synthetic decoder stack as a stage function: hidden in -> the stage's
     quantised linears (one FFI crossing, squeezellm_amd.decode.OpSequence) -> hidden out.
@@ -93,7 +171,10 @@ class DecodeStage:
         """graph=True (GPU stages): the whole stage -- input cast, arena clear, every kernel of the
         pass, the norm and the output cast -- is captured ONCE into a HIP graph and replayed per
         tick from static input / output buffers, so a tick costs one graph launch on the host
-        instead of ~10 eager torch calls (which would be host-bound at 4-10 layers per GPU)."""
+        instead of ~10 eager torch calls (which would be host-bound at 4-10 layers per GPU).
+        NOTE the aliasing that comes with it: with a graph, every call returns THE SAME output buffer
+        (`out_static`), overwritten by the next call -- clone it to keep a tick's result (RingPipeline
+        copies it into its gather buffer at once).  If the capture fails the stage runs eagerly."""
         from .decode import OpSequence
 
         self.hidden, self.device = hidden, device
@@ -119,9 +200,13 @@ class DecodeStage:
             with torch.cuda.stream(side):
                 self._eager(self.h_static)  # warm-up outside the capture
             torch.cuda.current_stream(device).wait_stream(side)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out_static = self._eager(self.h_static)
+            try:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.out_static = self._eager(self.h_static)
+            except RuntimeError:  # capture not possible here (e.g. an allocator / library that cannot be captured): eager stage
+                self.graph = None
+                torch.cuda.synchronize(device)
 
     def _eager(self, h_in: torch.Tensor) -> torch.Tensor:
         self.x_hidden.copy_(h_in)  # fp16 -> fp32 (the x.float() of quant.py:223)

@@ -259,3 +259,41 @@ def test_fused_forward_keeps_one_workspace_across_batch_sizes(gpu):
         sizes.append(next(iter(mod._ws.values())).numel())
         assert int(next(iter(mod._ws.values())).count_nonzero()) == 0
     assert sizes == sorted(sizes) and sizes[-1] == 8 * 12 * N
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("kind", ["dense", "hybrid"])
+@pytest.mark.parametrize("rows", [1, 3])
+@pytest.mark.parametrize("poison", ["nan", "+inf", "-inf", "+inf,-inf", "nan,+inf"])
+def test_fused_linear_propagates_nan_and_inf_like_the_operator_path(gpu, bits, kind, rows, poison):
+    """Non-finite activations: the reference's path (fp32 atomics into `mul`, squeezellm/quant.py:214-223) carries NaN
+    and +-inf through to the output; the fused linear accumulates in integer fixed point and carries them in two
+    sticky flag bits of the word.  Same non-finite pattern as the four-launch path (column by column: NaN where
+    it is NaN, +-inf with the same sign), finite columns / rows unchanged, workspace left clean."""
+    import torch
+
+    from squeezellm_amd import quant, synth
+
+    K, N = 1024, 264
+    lay = synth.make_layer(K, N, bits, sparse_frac=0.0 if kind == "dense" else 0.01, topX=3 if kind == "hybrid" else 0,
+                           heavy_rows=2 if kind != "dense" else 0, bias=True, device=gpu, seed=77 + bits)
+    plain = quant.QuantLinearLUT.from_operands(lay)
+    fused = quant.QuantLinearLUT.from_operands(lay)
+    quant.fuse_quant_lut(fused)
+    g = torch.Generator(device=gpu).manual_seed(5)
+    x = torch.randn((rows, K), device=gpu, generator=g).half()
+    vals = {"nan": float("nan"), "+inf": float("inf"), "-inf": float("-inf")}
+    for j, name in enumerate(poison.split(",")):
+        x[rows - 1, 37 + 500 * j] = vals[name]  # (two poisons land in different K slices of the tile)
+    xin = x if rows > 1 else x.reshape(1, 1, K)
+    want = plain(xin).reshape(rows, N).float().cpu()
+    for rep in range(2):  # second call: the flags of the first must not linger in the workspace
+        got = fused(xin).reshape(rows, N).float().cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(want)), f"NaN pattern differs ({int(torch.isnan(got).sum())} vs {int(torch.isnan(want).sum())})"
+        assert torch.equal(torch.isposinf(got), torch.isposinf(want)) and torch.equal(torch.isneginf(got), torch.isneginf(want))
+        fin = torch.isfinite(want)
+        assert fin[: rows - 1].all(), "rows without poison stay finite"
+        assert torch.allclose(got[fin], want[fin], rtol=2e-3, atol=2e-3)
+    assert (~torch.isfinite(want[rows - 1])).all(), "a poisoned row is non-finite in every column"
+    ws = next(iter(fused._ws.values()))
+    assert int(ws.count_nonzero()) == 0, "workspace must be left zero-filled"

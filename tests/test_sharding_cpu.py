@@ -112,3 +112,73 @@ def test_ring_pipeline_world1_is_a_plain_loop():
     for _ in range(3):
         h = f(h)
     assert torch.allclose(pipe.h_in, h)
+
+
+# ---- column (N) sharding inside a layer: SURVEY.md 8(e) path 2 ----
+def _torch_case(bits, K, N, seed):
+    case = H.make_case(bits, K, N, sparse=0.03, topX=5, heavy_rows=2, seed=seed)
+    return case, {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k, v in case.items()}
+
+
+def _oracle_on(layer_t, x):
+    npl = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in layer_t.items()}
+    kind = "hybrid" if npl.get("full_rows") is not None else ("spmv" if npl.get("vals") is not None else "dense")
+    return np.asarray(H.oracle_ref(npl, x, np.zeros(npl["N"], np.float32), kind))
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_shard_layer_columns_partitions_the_result(bits, world):
+    """Slicing qweight / lookup_table / CSR rows / top-X rows by output column and concatenating the slices'
+    results reproduces the unsharded op exactly (no reduction across ranks)."""
+    K, N = 256, 328  # 5 blocks of 64 + a ragged one: uneven and (for world 8) empty ranges
+    case, lay = _torch_case(bits, K, N, seed=40 + bits)
+    x = np.random.default_rng(3).normal(size=K).astype(np.float32)
+    want = np.asarray(H.oracle_ref(case, x, np.zeros(N, np.float32), "hybrid"))
+    ranges = sharding.column_ranges(N, world)
+    assert ranges[0][0] == 0 and ranges[-1][1] == N and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    assert all(a % 64 == 0 for a, b in ranges if b > a)
+    parts, topx_seen = [], 0
+    for r in range(world):
+        sh = sharding.shard_layer_columns(lay, r, world)
+        assert sh["N"] == ranges[r][1] - ranges[r][0] and sh["qweight"].shape == (K // 32 * bits, sh["N"])
+        assert int(sh["rows"][0]) == 0 and int(sh["rows"][-1]) == sh["vals"].numel() == sh["cols"].numel()
+        topx_seen += 0 if sh["full_rows"] is None else sh["full_rows"].shape[1]
+        parts.append(_oracle_on(sh, x) if sh["N"] else np.zeros(0))
+    assert topx_seen == 5  # every top-X row belongs to exactly one rank
+    assert np.allclose(np.concatenate(parts), want, rtol=1e-12, atol=1e-14)  # (fp64 oracle; only the order of the terms differs)
+
+
+def _col_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _, lay = _torch_case(4, 256, 328, seed=44)
+    sh = sharding.shard_layer_columns(lay, rank, world)
+    op = sharding.ColumnParallelOp(lambda x: torch.from_numpy(_oracle_on(sh, x.numpy())).float(), 328, rank=rank,
+                                   world_size=world, device="cpu")
+    g = torch.Generator().manual_seed(9)
+    outs = [op(torch.randn(256, generator=g)).numpy().copy() for _ in range(3)]
+    q.put((rank, outs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_column_parallel_op_gloo_matches_single_process(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 100 + world
+    procs = [ctx.Process(target=_col_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    case, _ = _torch_case(4, 256, 328, seed=44)
+    g = torch.Generator().manual_seed(9)
+    for i in range(3):
+        x = torch.randn(256, generator=g).numpy()
+        want = np.asarray(H.oracle_ref(case, x, np.zeros(328, np.float32), "hybrid"))
+        for rank, outs in res:
+            assert outs[i].shape == (328,) and np.allclose(outs[i], want, rtol=1e-6, atol=1e-7), f"rank {rank} call {i}"
