@@ -76,8 +76,9 @@ def parse_args():
     ap.add_argument("--no-fuse", action="store_true",
                     help="one launch per linear (224 per token for 7B) instead of fusing the linears of a decoder "
                          "layer that read the same input (q/k/v, gate/up) into one launch each")
-    ap.add_argument("--parallel", default="auto", choices=["auto", "replicas", "pipeline"],
-                    help="N > 1: independent replicas (weak scaling) or layer-sharded ring pipeline")
+    ap.add_argument("--parallel", default="auto", choices=["auto", "replicas", "pipeline", "columns"],
+                    help="N > 1: independent replicas (weak scaling), layer-sharded ring pipeline, or every linear split by "
+                         "output column with one all-gather per launch group (the latency split; opt-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sub-records", action="store_true", help="skip the s45 / 13B-batch sub-records of the default run")
@@ -282,6 +283,23 @@ def parity_spot(seq, ys, ref_outs):
             "against": "C port of the reference kernels (oracle/sqllm_oracle.c), fp64 accumulation, same weights and inputs"}
 
 
+def torch_dequant_T(q, lut, bits):
+    """W^T [K, N] = lookup_table[n, idx[k, n]] on the CPU with torch ops only.  4-bit: the int32 words are viewed as
+    bytes, split into nibbles and used as the row index of a gather from the transposed codebook [16, N] (the
+    general unpacker + an int64 flat index measured 3-4x slower); 3-bit: the product's tensor-level unpacker."""
+    import torch
+
+    from squeezellm_amd import pack
+
+    if bits == 4:
+        K8, N = q.shape
+        b = q.view(torch.uint8).reshape(K8, N, 4)  # little-endian: byte j holds k = 2j (low nibble) and 2j + 1 (high)
+        idx = torch.stack((b & 15, b >> 4), dim=-1).reshape(K8, N, 8).permute(0, 2, 1).reshape(K8 * 8, N)
+    else:
+        idx = pack.unpack_qweight(q, bits)
+    return torch.gather(lut.t().contiguous(), 0, idx.to(torch.int64))
+
+
 def cpu_baseline_torch(layers, model_layers: int, budget_s: float = 6.0):
     """The reference-style CPU path (BASELINE.json configs[0] / north_star): the codebook gather
     W[n, k] = lookup_table[n, idx[k, n]] (indices unpacked by the product's tensor-level unpacker)
@@ -303,18 +321,14 @@ def cpu_baseline_torch(layers, model_layers: int, budget_s: float = 6.0):
         t0 = time.perf_counter()
         Ws = []
         for q, lut, bits, x in ops:
-            idx = pack.unpack_qweight(q, bits).to(torch.int64)   # [K, N]
-            # W[n, k] = lut[n, idx[k, n]]: flat take over the [N * 2^bits] table (a gather along dim 1 of an
-            # int64 [N, K] index walks it one element at a time: 7 s per decoder layer)
-            flat = (idx + torch.arange(idx.shape[1]).unsqueeze(0) * lut.shape[1]).t().contiguous()
-            W = lut.reshape(-1)[flat]                            # [N, K]
-            Ws.append(W)
-            _ = W @ x
+            WT = torch_dequant_T(q, lut, bits)                   # [K, N]
+            Ws.append(WT)
+            _ = x @ WT
         t1 = time.perf_counter()
         for _ in range(2):  # second pass: warm
             t2 = time.perf_counter()
-            for W, (_, _, _, x) in zip(Ws, ops):
-                _ = W @ x
+            for WT, (_, _, _, x) in zip(Ws, ops):
+                _ = x @ WT
             t3 = time.perf_counter()
         t_deq.append(t1 - t0)
         t_mm.append(t3 - t2)
@@ -339,7 +353,7 @@ def cpu_leg_config1(budget_s: float = 10.0):
     import numpy as np
     import torch
 
-    from squeezellm_amd import pack, synth
+    from squeezellm_amd import synth
 
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
@@ -355,14 +369,12 @@ def cpu_leg_config1(budget_s: float = 10.0):
         t0 = time.perf_counter()
         Ws = []
         for l, x in zip(layers, xs):
-            idx = pack.unpack_qweight(l["qweight"], 4).to(torch.int64)
-            flat = (idx + torch.arange(l["N"]).unsqueeze(0) * 16).t().contiguous()
-            W = l["lookup_table"].reshape(-1)[flat]
-            Ws.append(W)
-            _ = (x @ W.t()).to(torch.float16) + l["bias"]
+            WT = torch_dequant_T(l["qweight"], l["lookup_table"], 4)
+            Ws.append(WT)
+            _ = (x @ WT).to(torch.float16) + l["bias"]
         t1 = time.perf_counter()
-        for W, l, x in zip(Ws, layers, xs):
-            _ = (x @ W.t()).to(torch.float16) + l["bias"]
+        for WT, l, x in zip(Ws, layers, xs):
+            _ = (x @ WT).to(torch.float16) + l["bias"]
         t2 = time.perf_counter()
         t_deq.append(t1 - t0)
         t_mm.append(t2 - t1)
@@ -562,8 +574,8 @@ def main():
     mode = args.parallel
     if mode == "auto":
         mode = "pipeline" if (world > 1 and args.config.startswith("65b")) else "replicas"
-    if world == 1 and args.parallel != "pipeline":
-        mode = "replicas"  # (an explicit --parallel pipeline on one GPU runs a ring of one stage)
+    if world == 1 and args.parallel not in ("pipeline", "columns"):
+        mode = "replicas"  # (an explicit --parallel pipeline / columns on one GPU runs the degenerate one-rank form)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -579,6 +591,21 @@ def main():
         blocks, seq, layers = m["blocks"], m["seq"], m["layers"]
         bytes_per_op = m["bytes_per_op"]
         tokens_per_step = 1
+    elif mode == "columns":
+        # every rank builds the same full operands (same seeds), keeps its column slices: 1 / world of every layer
+        layers = build_layers(cfg, dev, 0, model_layers)
+        bytes_per_op = [synth.layer_bytes(l, 1) for l in layers]
+        gen = torch.Generator(device=dev).manual_seed(1234)  # the same activations on every rank
+        xs, _ = decoder_inputs(layers, dev, gen)
+        cpass = sharding.ColumnParallelPass(layers, xs, rank=rank, world_size=world, device=dev)
+        del layers
+        torch.cuda.empty_cache()
+        layers = []
+        blocks = time_blocks(cpass.step, sync, args.steps, args.warmup, args.repeats)
+        tokens_per_step = 1
+        seq, m = None, None
+        extra["column_parallel"] = {"launch_groups": len(cpass.groups), "collectives_per_token": len(cpass.groups) if world > 1 else 0,
+                                    "graph_captured": cpass.graph is not None}
     else:
         lo, hi = sharding.partition_layers(model_layers, world)[rank]
         layers = build_layers(cfg, dev, lo, hi)
@@ -615,7 +642,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "strong" if mode == "pipeline" else "weak",
+        "scaling": "strong" if mode in ("pipeline", "columns") else "weak",
         "vs_baseline": None,  # BASELINE.md holds no published number for this metric
         "dtype": "f32",  # fp32 LUT values, fp32 activations, fp32 accumulate (3/4-bit integer indices)
         "data": "synthetic",
@@ -628,16 +655,19 @@ def main():
             "config_name": args.config,
             "launch": (args.launch + (", one launch per linear" if args.no_fuse else
                                       ", linears sharing an input (q/k/v, gate/up) fused into one launch each"))
-            if mode == "replicas" else "sequence + ring all-gather",
+            if mode == "replicas" else ("column-sharded linears, one all-gather of the mul slices per launch group" if mode == "columns"
+                                        else "sequence + ring all-gather"),
             "launches_per_token": seq.n_groups if mode == "replicas" else None,
             "parallelism": "single GPU" if world == 1 else (
                 f"dp{world}: independent token streams, one full model replica per GPU, no data-path collective"
                 if mode == "replicas" else
-                f"pp{world}: layer-sharded ring pipeline, RCCL all-gather of the hidden state per tick"),
+                (f"tp{world} by output column: every GPU holds 1/{world} of every linear, RCCL all-gather of the mul slices per launch group"
+                 if mode == "columns" else
+                 f"pp{world}: layer-sharded ring pipeline, RCCL all-gather of the hidden state per tick")),
             "world_size": world,
             "rccl_ranks": dist.get_world_size() if use_dist else 0,  # 0: no process group (single process)
             "ops_per_token": model_layers * per_layer,
-            "algorithmic_bytes_per_token": int(sum(bytes_per_op)) if mode == "replicas" else None,
+            "algorithmic_bytes_per_token": int(sum(bytes_per_op)) if mode in ("replicas", "columns") else None,
         },
     }
     result.update(extra)
@@ -651,6 +681,10 @@ def main():
             if args.per_shape:
                 print(json.dumps(m["per_layer_us"], indent=1), file=sys.stderr)
         headline_default = args.config == "7b-w4-s0" and args.layers is None and not args.no_fuse and args.launch == "graph"
+        # (the drop-in legs run first: the CPU legs leave 128-256 OpenMP / torch worker threads spinning for a while,
+        # which slows the eager Python path of forward_eager several-fold)
+        if headline_default and not args.no_sub_records:
+            result["drop_in"] = drop_in_legs(layers, m["xs"], dev, args, sync, model_layers, per_layer)
         if not args.no_cpu_baseline:
             # value = the C port of the kernels' algorithm on the host cores (kind "port"); the reference-style
             # torch paths BASELINE.json names (dequant + matmul, matmul alone) ride along in `paths`
@@ -668,8 +702,6 @@ def main():
             }
             if headline_default:
                 result["cpu_baseline"]["config1_opt1.3b_seq128"] = cpu_leg_config1()
-        if headline_default and not args.no_sub_records:
-            result["drop_in"] = drop_in_legs(layers, m["xs"], dev, args, sync, model_layers, per_layer)
         # release the headline model before the sub-records build theirs
         del m, seq, layers
         torch.cuda.empty_cache()

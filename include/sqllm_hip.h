@@ -126,12 +126,11 @@ int sqllm_profile_groups(const sqllm_op* ops, const int32_t* group_sizes, int32_
  * Accumulation runs in 2^-28 fixed point inside the workspace (so that one returning atomic both
  * deposits a partial sum and counts it): every partial sum is clamped to +-131072 (2 x the
  * largest finite fp16), i.e. results are exact to well below one fp16 ulp wherever the fp16 result
- * is finite.  Non-finite partial sums are carried by two sticky flag bits of the accumulator word:
- * a column that received a NaN comes out NaN, one that received infinities comes out +-inf by the
- * sign of its sum (NaN if infinities of both signs met) -- the same pattern the operator path's
- * fp32 atomics produce.  The CSR operands must be consistent (rows[N] == nnz, rows non-decreasing):
+ * is finite.  Non-finite partial sums are carried by three sticky flag bits of the accumulator word:
+ * a column that received a NaN comes out NaN, one that received +inf / -inf comes out +inf / -inf
+ * (NaN if infinities of both signs met) -- the same pattern the operator path's fp32 atomics produce.  The CSR operands must be consistent (rows[N] == nnz, rows non-decreasing):
  * completion is detected by counting the contributions `rows` announces.  Shapes whose columns
- * could receive more than 127 partial sums (K slices + K / 1024 + 2 CSR chunks) are rejected with
+ * could receive more than 63 partial sums (K slices + K / 1024 + 2 CSR chunks) are rejected with
  * SQLLM_E_SHAPE.
  * ------------------------------------------------------------------------------------------- */
 typedef struct sqllm_linear {

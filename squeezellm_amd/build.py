@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_NAME = "libsqllm_hip.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
-SOURCES = ["sqllm_kernels.hip", "sqllm_stream.hip", "sqllm_capi.hip"]
+SOURCES = ["sqllm_kernels.hip", "sqllm_stream.hip", "sqllm_pair.hip", "sqllm_capi.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("sqllm_kernels.h", "sqllm_decode.h", "sqllm_roles.h")] + [os.path.join(INCLUDE, "sqllm_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

@@ -33,6 +33,8 @@ struct Knobs {
   std::atomic<int> scratch_in_capture{1};  // stream-ordered scratch also while the stream is capturing (graph memory nodes)
   std::atomic<int> sparse_transpose{1};  // wide batches: the CSR role reads a transposed copy of vec (stream-ordered scratch)
   std::atomic<int> validate_csr{0};    // debug: check rows[] on the device before every launch that carries a CSR term
+  std::atomic<int> pair4{-1};          // 4-bit batch-1 operator launches on the column-pair-table kernel (sqllm_pair.hip): -1 default, 0 / 1
+  std::atomic<int> pair4_min_mb{12};   // ... from this many MB of packed weights per launch (below it the fused kernel's small tables win)
   std::atomic<int> stream{-1};         // batch-1 operator launches on the streaming kernel: -1 = default (off), 0 / 1
   std::atomic<void*> timeline{nullptr};  // measurement build: per-workgroup timestamp buffer
 };
@@ -120,7 +122,8 @@ int validate_csr_values(const sqllm_op* op, sqllm_stream_t stream) {
 // workgroups exist (1-3 per CU, 8 waves each, of the 4 that fit: the 7B shapes hold only
 // ~32-90 KiB of weights per CU, so the grid must be wide rather than deep).  A slice is a whole
 // number of workgroup steps (waves x 4 units) so only the last slice has a ragged end.
-void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1) {
+void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1, int max_slices = sqllm::kMaxSlices,
+               int waves = sqllm::kWaves) {
   const int kK = (op->bits == 4) ? 8 : 32;
   memset(gm, 0, sizeof(*gm));
   gm->K = op->K;
@@ -128,8 +131,8 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1)
   gm->batch = op->batch <= 0 ? 1 : op->batch;
   gm->col_tiles = (op->N + sqllm::kTileN - 1) / sqllm::kTileN;
   gm->units_total = op->K / kK;
-  const int step = sqllm::kWaves * 4;  // units one workgroup step covers
-  int upw = knobs().groups_per_wave.load(std::memory_order_relaxed) * sqllm::kWaves;
+  const int step = waves * 4;  // units one workgroup step covers
+  int upw = knobs().groups_per_wave.load(std::memory_order_relaxed) * waves;
   if (upw <= 0) {
     int target = knobs().target_wgs.load(std::memory_order_relaxed);
     if (target <= 0) {
@@ -140,10 +143,11 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1)
       const double mb = (double)op->K * op->N * op->bits / 8.0 / 1e6;
       const bool alone = ops_in_launch <= 1;
       target = (mb <= 12.0 ? (alone ? 2 : 1) : (alone ? 4 : 3)) * cu_count();
+      if (waves > sqllm::kWaves) target = target * sqllm::kWaves / waves;  // (16-wave workgroups: half as many, twice the rows each)
     }
     int slices = (target + gm->col_tiles / 2) / gm->col_tiles;
     if (slices < 1) slices = 1;
-    if (slices > sqllm::kMaxSlices) slices = sqllm::kMaxSlices;
+    if (slices > max_slices) slices = max_slices;
     upw = (gm->units_total + slices - 1) / slices;
   }
   upw = (upw + step - 1) / step * step;
@@ -235,6 +239,20 @@ void make_plan_cols(const sqllm_op* op, sqllm::KernelGeom* gm) {
 int cols_min_batch_of() {
   const int v = knobs().cols_min_batch.load(std::memory_order_relaxed);
   return v > 0 ? v : 2;
+}
+
+// Column-pair-table kernel (sqllm_pair.hip): 4-bit operator launches at batch 1 whose packed weights are large
+// enough to pay for the 64 KiB tables (option pair4_min_mb, MB per launch).
+bool takes_pair4_path(const sqllm_op* ops, int n) {
+  const int v = knobs().pair4.load(std::memory_order_relaxed);
+  if (v == 0 || ops[0].bits != 4) return false;
+  if (v < 0) return false;  // default: off until measured
+  double mb = 0.0;
+  for (int i = 0; i < n; ++i) {
+    if (ops[i].batch > 1 || (ops[i].N % 4) != 0) return false;
+    mb += (double)ops[i].K * ops[i].N / 2.0 / 1e6;
+  }
+  return mb >= (double)knobs().pair4_min_mb.load(std::memory_order_relaxed);
 }
 
 // Streaming batch-1 kernel (sqllm_stream.hip): does this launch take it, and with what geometry?
@@ -366,6 +384,8 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "scratch_in_capture")) { knobs().scratch_in_capture.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { knobs().validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "stream")) { knobs().stream.store(value > 1 ? -1 : value); return SQLLM_OK; }  // 0 off, 1 on, 2 default
+  if (!strcmp(name, "pair4")) { knobs().pair4.store(value > 1 ? -1 : value); return SQLLM_OK; }    // 0 off, 1 on, 2 default
+  if (!strcmp(name, "pair4_min_mb")) { knobs().pair4_min_mb.store(value); return SQLLM_OK; }
 #ifdef SQLLM_ABLATION_BUILD
   if (!strcmp(name, "ablate")) { knobs().ablate.store(value); return SQLLM_OK; }
   if (!strcmp(name, "ablate_csr")) { knobs().ablate_csr.store(value); return SQLLM_OK; }
@@ -386,6 +406,8 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "scratch_in_capture")) { *value = knobs().scratch_in_capture.load(); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { *value = knobs().validate_csr.load(); return SQLLM_OK; }
   if (!strcmp(name, "stream")) { const int v = knobs().stream.load(); *value = v < 0 ? 2 : v; return SQLLM_OK; }
+  if (!strcmp(name, "pair4")) { const int v = knobs().pair4.load(); *value = v < 0 ? 2 : v; return SQLLM_OK; }
+  if (!strcmp(name, "pair4_min_mb")) { *value = knobs().pair4_min_mb.load(); return SQLLM_OK; }
   return SQLLM_E_OPTION;
 }
 
@@ -565,6 +587,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     }
     ops = tmp;
   }
+  const bool pair4 = !lin && takes_pair4_path(ops, n);
   sqllm::LaunchArgs a;
   a.linear = lin != nullptr;
   a.ev_start = e0;
@@ -596,7 +619,11 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
 #ifdef SQLLM_ABLATION_BUILD
     if (!lin) sg.bias = static_cast<const float*>(knobs().timeline.load(std::memory_order_relaxed));
 #endif
-    make_plan(op, &sg.gm, n);
+    // fused linear: a column's K slices + the CSR chunks its row can be spread over must fit the 6-bit count
+    const int csr_bound = (op->rows && op->nnz > 0) ? op->K / sqllm::kCsrChunk + 2 : 0;
+    make_plan(op, &sg.gm, n, lin ? (sqllm::kMaxContrib - csr_bound > 1 ? sqllm::kMaxContrib - csr_bound : 1) : sqllm::kMaxSlices,
+              pair4 ? 16 : sqllm::kWaves);
+    if (pair4) sg.gm.sparse_last = 0;
     if (lin) {
       // accumulate into the workspace plane; op->mul is the fp16 result
       sg.y = reinterpret_cast<float*>(lin[i].workspace);
@@ -617,6 +644,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
   }
   for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
   for (int i = n; i < sqllm::kMaxSegments; ++i) memset(&a.ga.seg[i], 0, sizeof(sqllm::Segment));
+  if (pair4) return static_cast<int>(sqllm::launch_pair4(a, static_cast<hipStream_t>(stream)));
   return static_cast<int>(sqllm::launch_fused(ops[0].bits, a, static_cast<hipStream_t>(stream)));
 }
 

@@ -441,7 +441,7 @@ __device__ __forceinline__ void step3_pair(const u32x4 (&slot)[3], float xslot0,
 // workgroup here: measured +4.5 us per launch) and no launch-wide counter (a last-arriver that
 // must then touch all N columns measured +4-11 us per launch).
 //
-// Contributions are clamped to +-2^17 (twice the largest finite fp16) so that the at most 127 of
+// Contributions are clamped to +-2^17 (twice the largest finite fp16) so that the at most 63 of
 // them a column can receive stay inside the 55-bit field; sums beyond that are not finite in
 // fp16 anyway.  Rounding: 2^-28 absolute per contribution, far below one fp16 ulp of any normal
 // fp16 result.
@@ -450,9 +450,9 @@ __device__ __forceinline__ void step3_pair(const u32x4 (&slot)[3], float xslot0,
 // (squeezellm/quant.py:214-223: zeros, op, cast); an integer sum cannot, so the word's two top bits
 // are STICKY FLAGS, set with an atomic OR by a contributor whose partial sum is not finite BEFORE
 // its counted add (atomics on one address are totally ordered, so whoever completes the count sees
-// every flag): bit 63 = a NaN was contributed, bit 62 = an infinity was (it also contributes its
-// clamped +-2^17, so the sign of the sum tells +inf from -inf, and a sum of zero -- infinities of
-// both signs -- is NaN, as inf - inf is).  The count keeps bits 55-61 (at most 127 contributions).
+// every flag): bit 63 = a NaN was contributed, bit 62 = a +inf, bit 61 = a -inf (infinities of both
+// signs make a NaN, as inf - inf does); a non-finite value adds nothing to the sum.  The count keeps
+// bits 55-60 (at most 63 contributions).
 // (Only the wide-span CSR fallback adds values uncounted; while such a word is transiently negative an
 // OR may be lost -- a NaN is then reported as a finite number, as before round 3.)
 // ------------------------------------------------------------------------------------------------
@@ -460,10 +460,10 @@ typedef unsigned long long u64;
 constexpr int kFixShift = 28;
 constexpr int kCountShift = 55;
 constexpr u64 kCountUnit = 1ull << kCountShift;
-constexpr u64 kNanFlag = 1ull << 63, kInfFlag = 1ull << 62, kFlagMask = kNanFlag | kInfFlag;
+constexpr u64 kNanFlag = 1ull << 63, kPosInfFlag = 1ull << 62, kNegInfFlag = 1ull << 61, kFlagMask = kNanFlag | kPosInfFlag | kNegInfFlag;
 
 __device__ __forceinline__ u64 to_fixed(float v) {
-  v = (v != v) ? 0.f : __builtin_fminf(__builtin_fmaxf(v, -131072.f), 131072.f);  // (a NaN rides in the flag, not in the sum)
+  v = (__builtin_fabsf(v) <= 3.402823466e38f) ? __builtin_fminf(__builtin_fmaxf(v, -131072.f), 131072.f) : 0.f;  // (NaN / inf ride in the flags)
   return (u64)(long long)__builtin_rintf(v * (float)(1 << kFixShift));
 }
 
@@ -471,7 +471,7 @@ __device__ __forceinline__ u64 to_fixed(float v) {
 __device__ __forceinline__ void flag_nonfinite(u64* word, float v) {
   if (!(__builtin_fabsf(v) <= 3.402823466e38f))
     __hip_atomic_fetch_or(reinterpret_cast<__attribute__((address_space(1))) u64*>(reinterpret_cast<uintptr_t>(word)),
-                          (v != v) ? kNanFlag : kInfFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                          (v != v) ? kNanFlag : (v > 0.f ? kPosInfFlag : kNegInfFlag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // CSR chunks (kCsrChunk consecutive non-zeros each) holding part of a row that spans [r0, r1)
@@ -489,8 +489,9 @@ __device__ __forceinline__ void column_done(const Segment& sg, u64* word, u64 to
   if ((unsigned)count != target) return;
   const long long sfix = (long long)(total - (count << kCountShift));
   float v = (float)sfix * (1.f / (float)(1 << kFixShift));
-  if (flags & kNanFlag) v = __builtin_nanf("");
-  else if (flags & kInfFlag) v = sfix > 0 ? __builtin_inff() : sfix < 0 ? -__builtin_inff() : __builtin_nanf("");
+  if ((flags & kNanFlag) || (flags & (kPosInfFlag | kNegInfFlag)) == (kPosInfFlag | kNegInfFlag)) v = __builtin_nanf("");
+  else if (flags & kPosInfFlag) v = __builtin_inff();
+  else if (flags & kNegInfFlag) v = -__builtin_inff();
   v += sg.bias ? sg.bias[c] : 0.f;
   reinterpret_cast<_Float16*>(sg.out16)[at] = (_Float16)v;
   atomicExch(word, 0ull);  // result unused: a plain atomic store

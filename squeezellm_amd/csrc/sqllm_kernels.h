@@ -29,7 +29,7 @@ constexpr int kTopxRows = 128;     // k's per top-X slab
 constexpr int kTopxLds = 1024;     // topX up to which slab sums are kept in LDS
 constexpr int kMaxBatchTile = 8;   // batch rows handled per weight pass
 constexpr int kMaxSlices = 120;    // K slices per column tile
-constexpr int kMaxContrib = 127;   // fused linear: contributions one column may receive (7-bit count under the two non-finite flags)
+constexpr int kMaxContrib = 63;    // fused linear: contributions one column may receive (6-bit count under the three non-finite flags)
 
 // LDS floats of one kernel instantiation: max over roles of
 //   dense: codebooks 4 column sub-tables * lut_entries * 32 slots (2 copies of 16 lanes) PLUS the
@@ -135,6 +135,7 @@ inline int batch_tile(int batch) { return batch <= 1 ? 1 : batch == 2 ? 2 : batc
 inline int mfma_row_blocks(int batch) { return batch <= 16 ? 1 : batch <= 32 ? 2 : 4; }
 
 hipError_t launch_fused(int bits, const LaunchArgs& a, hipStream_t stream);
+hipError_t launch_pair4(const LaunchArgs& a, hipStream_t stream);  // 4-bit, batch 1, operator launches: column-pair tables, 16-wave workgroups
 // `ga`: the sparse roles of the launch (block0[] = prefix over csr + top-X workgroups only)
 hipError_t launch_stream(int bits, const StreamArgs& sa, const GroupArgs& ga, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
                          int ablate);

@@ -156,6 +156,87 @@ class ColumnParallelOp:
         return torch.cat([self.buf[r, : b - a] for r, (a, b) in enumerate(self.ranges)])
 
 
+class ColumnParallelPass:
+    """A whole decode pass with every linear split by output column over the ranks (the latency split): per
+    launch group (q/k/v, o, gate/up, down) this rank's column slices run as ONE kernel launch into a
+    contiguous arena slice, then ONE all-gather of that slice rebuilds the group's `mul` vectors on every rank.
+    `layers`: the FULL operand dicts (identical on every rank: same seeds / same checkpoint); `xs`: one input
+    tensor per linear (linears sharing an input share the tensor, as in decode.OpSequence).
+    graph=True captures the pass -- kernels AND collectives -- into one HIP graph where the backend allows it
+    (RCCL collectives are capturable); otherwise the pass runs eagerly, one FFI crossing + one collective per
+    group."""
+
+    def __init__(self, layers: Sequence[dict], xs: Sequence[torch.Tensor], *, rank: int, world_size: int, device, group=None,
+                 graph: bool = True):
+        from .decode import OpSequence
+
+        self.rank, self.world, self.group, self.device = rank, world_size, group, device
+        # launch groups = runs of consecutive linears reading the same input tensor (up to 4)
+        groups, cur = [], []
+        for i, x in enumerate(xs):
+            if cur and len(cur) < 4 and xs[cur[0]] is x and layers[cur[0]]["K"] == layers[i]["K"]:
+                cur.append(i)
+            else:
+                if cur:
+                    groups.append(cur)
+                cur = [i]
+        if cur:
+            groups.append(cur)
+        self.groups = groups
+        self.local, self.gathered, self.seqs, self.widths = [], [], [], []
+        for grp in groups:
+            shards = [shard_layer_columns(layers[i], rank, world_size) for i in grp]
+            # every rank's slice of linear i is padded to the widest rank's, so that the collective is uniform
+            widths = [max(b - a for a, b in column_ranges(layers[i]["N"], world_size)) for i in grp]
+            mine = torch.zeros(sum(widths), device=device, dtype=torch.float32)
+            ys, off = [], 0
+            for sh, w in zip(shards, widths):
+                ys.append(mine[off:off + sh["N"]])
+                off += w
+            live = [(sh, xs[i], y) for sh, i, y in zip(shards, grp, ys) if sh["N"] > 0]
+            self.seqs.append(OpSequence([t[0] for t in live], [t[1] for t in live], [t[2] for t in live], fuse_shared_input=True) if live else None)
+            self.local.append(mine)
+            self.gathered.append(torch.zeros((world_size, sum(widths)), device=device, dtype=torch.float32))
+            self.widths.append(widths)
+        self.graph = None
+        if graph and torch.device(device).type == "cuda":
+            try:
+                side = torch.cuda.Stream(device)
+                side.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(side):
+                    self._eager()
+                torch.cuda.current_stream(device).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._eager()
+                self.graph = g
+            except RuntimeError:
+                self.graph = None
+                torch.cuda.synchronize(device)
+
+    def _eager(self) -> None:
+        for seq, mine, full in zip(self.seqs, self.local, self.gathered):
+            mine.zero_()  # (operator semantics: mul += ...)
+            if seq is not None:
+                seq.launch()
+            if self.world == 1:
+                full[0].copy_(mine)
+            else:
+                dist.all_gather_into_tensor(full, mine, group=self.group)
+
+    def step(self) -> None:
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._eager()
+
+    def result(self, gi: int, j: int, N: int) -> torch.Tensor:
+        """The full `mul` of the j-th linear of launch group gi (N columns), assembled from the gathered slices."""
+        off = sum(self.widths[gi][:j])
+        parts = [self.gathered[gi][r, off:off + (b - a)] for r, (a, b) in enumerate(column_ranges(N, self.world))]
+        return torch.cat(parts)
+
+
 class DecodeStage:
     """This rank's slice of a synthetic decoder stack as a stage function: hidden in -> the stage's
     quantised linears (one FFI crossing, squeezellm_amd.decode.OpSequence) -> hidden out.

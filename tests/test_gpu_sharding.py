@@ -1,0 +1,61 @@
+"""GPU side of the column (N) split (squeezellm_amd/sharding.py, SURVEY.md 8(e) path 2): the HIP kernels on
+column-sharded operands, every shard's result concatenated, against the unsharded op and the oracle; and the
+one-rank form of the column-parallel pass (the collective path itself is covered with gloo on CPU)."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _npl(lay):
+    import torch
+
+    return {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in lay.items()}
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_column_shards_run_on_the_kernels(gpu, bits, world):
+    import torch
+
+    from squeezellm_amd import decode, sharding, synth
+
+    K, N = 2048, 1096  # 17 blocks of 64 + a ragged one
+    lay = synth.make_layer(K, N, bits, sparse_frac=0.01, topX=6, heavy_rows=3, device=gpu, seed=21 + bits)
+    x = torch.randn(K, device=gpu)
+    ref = H.c_matvec(H.c_oracle(), _npl(lay), x.cpu().numpy(), np.zeros(N, np.float32), batched=False)
+    parts = []
+    for r in range(world):
+        sh = sharding.shard_layer_columns(lay, r, world)
+        y = torch.zeros(sh["N"], device=gpu)
+        if sh["N"]:
+            decode.OpSequence([sh], [x], [y]).launch()
+        parts.append(y)
+    torch.cuda.synchronize()
+    got = torch.cat(parts).cpu().numpy()
+    assert got.shape == (N,) and H.rel_err(got, ref) <= 2e-5
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_column_parallel_pass_one_rank(gpu, graph):
+    import torch
+
+    from squeezellm_amd import sharding, synth
+
+    spec = [("q", 1024, 512), ("k", 1024, 512), ("v", 1024, 512), ("o", 512, 1024), ("g", 1024, 1408), ("u", 1024, 1408), ("d", 1408, 1024)]
+    layers = [synth.make_layer(K, N, 4, sparse_frac=0.01, topX=4, heavy_rows=1, device=gpu, seed=60 + i) for i, (_, K, N) in enumerate(spec)]
+    xh, xo, xm = torch.randn(1024, device=gpu), torch.randn(512, device=gpu), torch.randn(1408, device=gpu)
+    xs = [xh, xh, xh, xo, xh.clone(), None, xm]
+    xs[5] = xs[4]
+    cp = sharding.ColumnParallelPass(layers, xs, rank=0, world_size=1, device=gpu, graph=graph)
+    assert cp.groups == [[0, 1, 2], [3], [4, 5], [6]] and (cp.graph is not None) == graph
+    cp.step()
+    cp.step()  # (a second pass starts from zeroed slices again)
+    torch.cuda.synchronize()
+    lib = H.c_oracle()
+    for gi, grp in enumerate(cp.groups):
+        for j, i in enumerate(grp):
+            ref = H.c_matvec(lib, _npl(layers[i]), xs[i].cpu().numpy(), np.zeros(layers[i]["N"], np.float32), batched=False)
+            assert H.rel_err(cp.result(gi, j, layers[i]["N"]).cpu().numpy(), ref) <= 2e-5
