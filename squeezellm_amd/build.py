@@ -20,7 +20,10 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_NAME = "libsqllm_hip.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
-SOURCES = ["sqllm_kernels.hip", "sqllm_stream.hip", "sqllm_pair.hip", "sqllm_capi.hip"]
+SOURCES = ["sqllm_kernels.hip", "sqllm_capi.hip"]
+# measured-and-not-adopted kernels (round 3: the streaming batch-1 kernel, the column-pair-table kernel): part of the
+# MEASUREMENT library only, selected there with the options "stream" / "pair4"
+EXPERIMENT_SOURCES = ["sqllm_stream.hip", "sqllm_pair.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("sqllm_kernels.h", "sqllm_decode.h", "sqllm_roles.h")] + [os.path.join(INCLUDE, "sqllm_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
@@ -57,9 +60,9 @@ ABLATION_LIB_PATH = os.path.join(HERE, ABLATION_LIB_NAME)
 VARIANT_ENV = ("SQLLM_WAVES", "SQLLM_PAIR3", "SQLLM_HALF_STAGES", "SQLLM_PAIR3_NOCONFLICT", "SQLLM_MFMA_VAR", "SQLLM_MFMA_FAKE")
 
 
-def _compile(out: str, extra, verbose: bool) -> str:
+def _compile(out: str, extra, verbose: bool, sources=None) -> str:
     cmd = [hipcc(), f"--offload-arch={ARCH}", *FLAGS, *extra, "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", out + ".tmp"]
+           *[os.path.join(CSRC, s) for s in (sources or SOURCES)], "-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -91,7 +94,7 @@ def build_ablation(verbose: bool = False, out: str | None = None) -> str:
         if os.environ.get(name):
             extra.append(f"-D{name}={int(os.environ[name])}")
     extra += os.environ.get("SQLLM_EXTRA_DEFINES", "").split()
-    return _compile(out, extra, verbose)
+    return _compile(out, extra, verbose, SOURCES[:-1] + EXPERIMENT_SOURCES + SOURCES[-1:])
 
 
 if __name__ == "__main__":

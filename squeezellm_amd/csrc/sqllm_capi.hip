@@ -244,6 +244,10 @@ int cols_min_batch_of() {
 // Column-pair-table kernel (sqllm_pair.hip): 4-bit operator launches at batch 1 whose packed weights are large
 // enough to pay for the 64 KiB tables (option pair4_min_mb, MB per launch).
 bool takes_pair4_path(const sqllm_op* ops, int n) {
+#ifndef SQLLM_ABLATION_BUILD
+  (void)ops; (void)n;
+  return false;
+#endif
   const int v = knobs().pair4.load(std::memory_order_relaxed);
   if (v == 0 || ops[0].bits != 4) return false;
   if (v < 0) return false;  // default: off until measured
@@ -257,6 +261,10 @@ bool takes_pair4_path(const sqllm_op* ops, int n) {
 
 // Streaming batch-1 kernel (sqllm_stream.hip): does this launch take it, and with what geometry?
 bool takes_stream_path(const sqllm_op* ops, int n) {
+#ifndef SQLLM_ABLATION_BUILD
+  (void)ops; (void)n;
+  return false;
+#endif
   const int v = knobs().stream.load(std::memory_order_relaxed);
   if (v == 0) return false;
   if (v < 0) return false;  // default: off until it beats the fused kernel on the box it is measured on
@@ -383,10 +391,11 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "sparse_transpose")) { knobs().sparse_transpose.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "scratch_in_capture")) { knobs().scratch_in_capture.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { knobs().validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
-  if (!strcmp(name, "stream")) { knobs().stream.store(value > 1 ? -1 : value); return SQLLM_OK; }  // 0 off, 1 on, 2 default
-  if (!strcmp(name, "pair4")) { knobs().pair4.store(value > 1 ? -1 : value); return SQLLM_OK; }    // 0 off, 1 on, 2 default
-  if (!strcmp(name, "pair4_min_mb")) { knobs().pair4_min_mb.store(value); return SQLLM_OK; }
 #ifdef SQLLM_ABLATION_BUILD
+  // the measured-and-not-adopted kernels (sqllm_stream.hip, sqllm_pair.hip) exist in the measurement library only
+  if (!strcmp(name, "stream")) { knobs().stream.store(value > 1 ? -1 : value); return SQLLM_OK; }  // 0 off, 1 on, 2 default (off)
+  if (!strcmp(name, "pair4")) { knobs().pair4.store(value > 1 ? -1 : value); return SQLLM_OK; }    // 0 off, 1 on, 2 default (off)
+  if (!strcmp(name, "pair4_min_mb")) { knobs().pair4_min_mb.store(value); return SQLLM_OK; }
   if (!strcmp(name, "ablate")) { knobs().ablate.store(value); return SQLLM_OK; }
   if (!strcmp(name, "ablate_csr")) { knobs().ablate_csr.store(value); return SQLLM_OK; }
 #endif
@@ -405,9 +414,11 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "sparse_transpose")) { *value = knobs().sparse_transpose.load(); return SQLLM_OK; }
   if (!strcmp(name, "scratch_in_capture")) { *value = knobs().scratch_in_capture.load(); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { *value = knobs().validate_csr.load(); return SQLLM_OK; }
+#ifdef SQLLM_ABLATION_BUILD
   if (!strcmp(name, "stream")) { const int v = knobs().stream.load(); *value = v < 0 ? 2 : v; return SQLLM_OK; }
   if (!strcmp(name, "pair4")) { const int v = knobs().pair4.load(); *value = v < 0 ? 2 : v; return SQLLM_OK; }
   if (!strcmp(name, "pair4_min_mb")) { *value = knobs().pair4_min_mb.load(); return SQLLM_OK; }
+#endif
   return SQLLM_E_OPTION;
 }
 
@@ -575,8 +586,10 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
 #ifdef SQLLM_ABLATION_BUILD
     sa.probe = static_cast<unsigned long long*>(knobs().timeline.load(std::memory_order_relaxed));
 #endif
+#ifdef SQLLM_ABLATION_BUILD
     return static_cast<int>(sqllm::launch_stream(ops[0].bits, sa, ga, static_cast<hipStream_t>(stream), e0, e1,
                                                  knobs().ablate.load(std::memory_order_relaxed)));
+#endif
   }
   sqllm_op tmp[sqllm::kMaxSegments];
   if (lin) {
@@ -644,7 +657,9 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
   }
   for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
   for (int i = n; i < sqllm::kMaxSegments; ++i) memset(&a.ga.seg[i], 0, sizeof(sqllm::Segment));
+#ifdef SQLLM_ABLATION_BUILD
   if (pair4) return static_cast<int>(sqllm::launch_pair4(a, static_cast<hipStream_t>(stream)));
+#endif
   return static_cast<int>(sqllm::launch_fused(ops[0].bits, a, static_cast<hipStream_t>(stream)));
 }
 

@@ -57,9 +57,16 @@ __device__ __forceinline__ void fma_pairs_interleaved(const f32x2 (&lo)[4], cons
 // One qweight row of this lane's 4 columns (two pairs) x 8 weights.
 //   lo = bytes { idx_a(k) | idx_b(k) << 4 : k = 0, 2, 4, 6 },  hi = the same for k = 1, 3, 5, 7
 // address of a lookup = [byte 1 = the byte, byte 0 = 8 * column group] (+ 128 for the lane's second pair).
+// Bank conflicts: ds_read_b64 is served 32 lanes (two 16-lane rows) at a time over 64 banks, and a lookup's
+// bank is (pair half, column group) -- the two rows of a half-wave would always meet on the same 32 banks with
+// different entries (a 2-way conflict on EVERY lookup).  So the odd lane rows take their two column pairs in
+// the opposite order: in each instruction the even rows read the low 128 bytes of the entry rows, the odd
+// rows the high ones.  `odd` selects (4 v_cndmask per row of 32 weights); acc[0] / acc[1] of an odd row hold
+// the pairs swapped and are swapped back once, before the rows are folded.
 template <int XL, int ABL>
-__device__ __forceinline__ void step4_pair(const u32x4& slot, float xv, uint32_t lane_off, f32x2 (&acc)[2]) {
-  uint32_t t[4] = {slot.x, slot.y, slot.z, slot.w};
+__device__ __forceinline__ void step4_pair(const u32x4& slot, float xv, bool odd, uint32_t off_first, uint32_t off_second,
+                                           f32x2 (&acc)[2]) {
+  uint32_t t[4] = {odd ? slot.z : slot.x, odd ? slot.w : slot.y, odd ? slot.x : slot.z, odd ? slot.y : slot.w};
   SQLLM_PIN4(t[0], t[1], t[2], t[3]);
   if constexpr (ABL & 2) {
     acc[0].x += __builtin_bit_cast(float, t[0] ^ t[1]) * xv;
@@ -71,16 +78,16 @@ __device__ __forceinline__ void step4_pair(const u32x4& slot, float xv, uint32_t
     const uint32_t a = t[2 * jp], b = t[2 * jp + 1];
     const uint32_t lo = (a & 0x0F0F0F0Fu) | ((b << 4) & 0xF0F0F0F0u);  // v_lshlrev + v_bfi
     const uint32_t hi = ((a >> 4) & 0x0F0F0F0Fu) | (b & 0xF0F0F0F0u);  // v_lshrrev + v_bfi
-    const int off = jp * 128;
+    const uint32_t lane_off = jp ? off_second : off_first;
     f32x2 wl[4], wh[4];
-    wl[0] = lds_read_f32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0400u) + off);
-    wh[0] = lds_read_f32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0400u) + off);
-    wl[1] = lds_read_f32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0500u) + off);
-    wh[1] = lds_read_f32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0500u) + off);
-    wl[2] = lds_read_f32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0600u) + off);
-    wh[2] = lds_read_f32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0600u) + off);
-    wl[3] = lds_read_f32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0700u) + off);
-    wh[3] = lds_read_f32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0700u) + off);
+    wl[0] = lds_read_f32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0400u));
+    wh[0] = lds_read_f32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0400u));
+    wl[1] = lds_read_f32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0500u));
+    wh[1] = lds_read_f32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0500u));
+    wl[2] = lds_read_f32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0600u));
+    wh[2] = lds_read_f32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0600u));
+    wl[3] = lds_read_f32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0700u));
+    wh[3] = lds_read_f32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0700u));
     fma_pairs_interleaved<XL>(wl, wh, xv, acc[jp]);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -156,7 +163,8 @@ __device__ __forceinline__ void dense_role_pair4(const float* x, const char* qba
     for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x2*>(dst + i * 256) = f32x2{ea[i], eb};
   }
   f32x2 acc[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
-  const uint32_t lane_off = 8u * (uint32_t)i16;
+  const bool odd = (grp & 1) != 0;
+  const uint32_t off_first = 8u * (uint32_t)i16 + (odd ? 128u : 0u), off_second = 8u * (uint32_t)i16 + (odd ? 0u : 128u);
   __syncthreads();  // tables visible
 
   auto decode_chunk = [&](int u, const u32x4 (&w)[NBUF], const float (&xs)[NBUF / 2]) __attribute__((always_inline)) {
@@ -164,8 +172,8 @@ __device__ __forceinline__ void dense_role_pair4(const float* x, const char* qba
     for (int s2 = 0; s2 < NBUF / 2; ++s2) {
       const int ua = u + 2 * s2 * STEP, ub = ua + STEP;
       const float xa = (ua + grp < u_end) ? xs[s2] : 0.f, xbv = (ub + grp < u_end) ? xs[s2] : 0.f;  // ragged slice end: zero x
-      if (ua < u_end) step4_pair<0, ABL>(w[2 * s2], xa, lane_off, acc);
-      if (ub < u_end) step4_pair<8, ABL>(w[2 * s2 + 1], xbv, lane_off, acc);
+      if (ua < u_end) step4_pair<0, ABL>(w[2 * s2], xa, odd, off_first, off_second, acc);
+      if (ub < u_end) step4_pair<8, ABL>(w[2 * s2 + 1], xbv, odd, off_first, off_second, acc);
     }
   };
   decode_chunk(u_wave, w0, x0);
@@ -182,6 +190,11 @@ __device__ __forceinline__ void dense_role_pair4(const float* x, const char* qba
   }
 
   // ---- fold the 4 lane rows, park in this wave's slab, take a ticket; the last wave sums the slabs ----
+  if (odd) {  // (odd rows accumulated their pairs in the opposite order)
+    const f32x2 tmp = acc[0];
+    acc[0] = acc[1];
+    acc[1] = tmp;
+  }
   float col[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {

@@ -269,3 +269,30 @@ def test_every_documented_option_round_trips():
         assert _lib.get_option(n) == 1, n
         _lib.set_option(n, before)
         assert _lib.get_option(n) == before, n
+
+
+def test_product_library_carries_no_measurement_variants():
+    """The ablation kernel instantiations, timeline probes, calibration kernels and the measured-and-not-adopted
+    kernels (streaming, column-pair tables) live in libsqllm_hip_ablation.so only; variant switches cannot be
+    compiled into the product (squeezellm_amd/build.py, csrc/sqllm_kernels.h)."""
+    import re
+    import subprocess
+
+    from squeezellm_amd import build as B
+
+    syms = subprocess.run(["nm", "-D", "--defined-only", B.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    for needle in ("sqllm_calib", "sqllm_debug_", "stream_matvec", "pair4_matvec"):
+        assert needle not in syms, needle
+    # sqllm_fused_matvec<BITS, BT, WAVES, ABL, LIN>: only ABL == 0 instantiations
+    abl = set(re.findall(r"sqllm_fused_matvecILi\dELi\dELi\d+ELi(\d+)E", syms))
+    assert abl == {"0"}, abl
+    # a variant switch without the measurement guard does not compile
+    import shutil
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if os.path.exists(hipcc):
+        r = subprocess.run([hipcc, f"--offload-arch={B.ARCH}", "-std=c++17", "-DSQLLM_PAIR3=0", f"-I{B.INCLUDE}", f"-I{B.CSRC}",
+                            "-fsyntax-only", "--cuda-device-only", os.path.join(B.CSRC, "sqllm_kernels.hip")], capture_output=True, text=True)
+        assert r.returncode != 0 and "SQLLM_ABLATION_BUILD" in r.stderr
+    with pytest.raises(ValueError):
+        B.build_ablation(out=B.LIB_PATH)
