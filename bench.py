@@ -610,10 +610,17 @@ def main():
         lo, hi = sharding.partition_layers(model_layers, world)[rank]
         layers = build_layers(cfg, dev, lo, hi)
         bytes_per_op = [synth.layer_bytes(l, 1) for l in layers]
-        stage = sharding.DecodeStage(layers, hidden, dev, seed=rank)
+        # the whole tick (stage kernels + all-gather + hand-over copy) as ONE captured graph where RCCL allows it;
+        # otherwise the stage replays its own graph and the collective runs eagerly
+        stage = sharding.DecodeStage(layers, hidden, dev, seed=rank, graph=False)
         g = torch.Generator(device=dev).manual_seed(99 + rank)
         h0 = torch.randn(hidden, device=dev, generator=g, dtype=torch.float16)
         pipe = sharding.RingPipeline(stage, hidden, rank=rank, world_size=world, device=dev, h0=h0)
+        whole_tick_captured = pipe.capture()
+        if not whole_tick_captured:
+            stage = sharding.DecodeStage(layers, hidden, dev, seed=rank, graph=True)
+            pipe = sharding.RingPipeline(stage, hidden, rank=rank, world_size=world, device=dev, h0=h0)
+        extra["pipeline_tick_captured"] = bool(whole_tick_captured)
         step = lambda: pipe.run(world)  # noqa: E731  W ticks = every sequence advances one token
         blocks = time_blocks(step, sync, args.steps, args.warmup, args.repeats)
         tokens_per_step = world

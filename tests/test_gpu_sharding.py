@@ -59,3 +59,31 @@ def test_column_parallel_pass_one_rank(gpu, graph):
         for j, i in enumerate(grp):
             ref = H.c_matvec(lib, _npl(layers[i]), xs[i].cpu().numpy(), np.zeros(layers[i]["N"], np.float32), batched=False)
             assert H.rel_err(cp.result(gi, j, layers[i]["N"]).cpu().numpy(), ref) <= 2e-5
+
+
+def test_ring_pipeline_whole_tick_capture_matches_eager(gpu):
+    """One rank: the tick captured as ONE graph (stage kernels + hand-over; the collective joins it at world > 1)
+    reproduces the eager ticks bit for bit over several turns of the ring."""
+    import torch
+
+    from squeezellm_amd import sharding, synth
+
+    hidden = 512
+    layers = [synth.make_layer(K, N, 4, sparse_frac=0.01, topX=2, heavy_rows=1, device=gpu, seed=80 + i)
+              for i, (K, N) in enumerate([(512, 512), (512, 1024), (1024, 512)])]
+    h0 = torch.randn(hidden, device=gpu).half()
+    outs = []
+    for captured in (False, True):
+        stage = sharding.DecodeStage(layers, hidden, gpu, seed=3, graph=False)
+        pipe = sharding.RingPipeline(stage, hidden, rank=0, world_size=1, device=gpu, h0=h0)
+        if captured:
+            assert pipe.capture() and pipe.capture()  # (idempotent)
+        seq = []
+        for _ in range(4):
+            seq.append(pipe.tick().clone())
+        torch.cuda.synchronize()
+        assert pipe.ticks == 4
+        outs.append(torch.stack(seq).float().cpu())
+    assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
+    # fp32 atomics: summation order may differ between the two runs; one fp16 ulp of slack
+    assert torch.allclose(outs[0], outs[1], rtol=2e-3, atol=2e-3)
