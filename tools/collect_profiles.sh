@@ -13,6 +13,8 @@ run() {  # name, rocprof args..., -- bench args
   rm -rf /tmp/prof_$name
   timeout 500 rocprofv3 "$@" > /tmp/prof_$name.log 2>&1
 }
+# the un-profiled default line of THIS box first: the profiles below are quoted beside it
+(cd $R && timeout 400 python bench.py --no-cpu-baseline --no-sub-records 2>/dev/null | grep '^{' > gpurun_out/${tag}_bench_samebox_7b-w4-s0.json)
 run kt_w4 --kernel-trace --stats -d /tmp/prof_kt_w4 -o x -- python $R/bench.py --steps 20 --no-cpu-baseline --no-sub-records
 grep '^{' /tmp/prof_kt_w4.log > $R/gpurun_out/${tag}_kt_w4.bench.json
 sum /tmp/prof_kt_w4 > $R/gpurun_out/${tag}_kt_w4.summary.txt
@@ -28,6 +30,11 @@ for pmc in FETCH_SIZE WRITE_SIZE; do
 done
 run pmc_fetch_w3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_pmc_fetch_w3 -o x -- python $R/bench.py --steps 3 --warmup 1 --launch sequence --no-cpu-baseline --no-sub-records --no-roofline --repeats 1 --config 7b-w3-s45
 sum /tmp/prof_pmc_fetch_w3 > $R/gpurun_out/${tag}_pmc_fetch_w3.summary.txt
+run pmc_fetch_w4s45 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_pmc_fetch_w4s45 -o x -- python $R/bench.py --steps 3 --warmup 1 --launch sequence --no-cpu-baseline --no-sub-records --no-roofline --repeats 1 --config 7b-w4-s45
+sum /tmp/prof_pmc_fetch_w4s45 > $R/gpurun_out/${tag}_pmc_fetch_w4s45.summary.txt
+run kt_w4s45 --kernel-trace --stats -d /tmp/prof_kt_w4s45 -o x -- python $R/bench.py --steps 20 --no-cpu-baseline --no-sub-records --config 7b-w4-s45
+grep '^{' /tmp/prof_kt_w4s45.log > $R/gpurun_out/${tag}_kt_w4s45.bench.json
+sum /tmp/prof_kt_w4s45 > $R/gpurun_out/${tag}_kt_w4s45.summary.txt
 run pmc_sq --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d /tmp/prof_pmc_sq -o x -- python $R/bench.py --steps 3 --warmup 1 --launch sequence --no-cpu-baseline --no-sub-records --no-roofline --repeats 1 --layers 8
 sum /tmp/prof_pmc_sq > $R/gpurun_out/${tag}_pmc_sq.summary.txt
 run pmc_sq_waits --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_ADDR_CONFLICT --kernel-trace -d /tmp/prof_pmc_sq_waits -o x -- python $R/bench.py --steps 3 --warmup 1 --launch sequence --no-cpu-baseline --no-sub-records --no-roofline --repeats 1 --layers 8
