@@ -266,8 +266,7 @@ bool takes_stream_path(const sqllm_op* ops, int n) {
   return false;
 #endif
   const int v = knobs().stream.load(std::memory_order_relaxed);
-  if (v == 0) return false;
-  if (v < 0) return false;  // default: off until it beats the fused kernel on the box it is measured on
+  if (v <= 0 || ops[0].bits != 4) return false;  // measurement library only, 4-bit only, off unless asked for
   const int kK = ops[0].bits == 4 ? 8 : 32;
   const uint32_t S = (uint32_t)((ops[0].K / kK + 3) / 4);
   uint64_t tiles = 0;

@@ -462,7 +462,10 @@ hipError_t launch_stream(int bits, const StreamArgs& sa, const GroupArgs& ga, hi
 #else
   (void)ablate;
 #endif
-  return bits == 4 ? launch_stream_inst<4, 0>(sa, ga, stream, e0, e1) : launch_stream_inst<3, 0>(sa, ga, stream, e0, e1);
+  // (the 3-bit instantiation compiles -- pair tables, two pieces, two workgroups per CU -- but needs 200+ VGPRs as
+  // written and was never tuned or measured: not offered)
+  if (bits != 4) return hipErrorInvalidValue;
+  return launch_stream_inst<4, 0>(sa, ga, stream, e0, e1);
 }
 
 }  // namespace sqllm
