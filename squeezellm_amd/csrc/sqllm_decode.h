@@ -70,6 +70,17 @@ __device__ __forceinline__ float row_bcast(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + P, 0xf, 0xf, true));
 }
 
+// generic DPP move: lanes the control leaves without a source (or the row mask disables) get `old`.
+// Controls used: 0x110 + n = row_shr:n, 0x130 / 0x138 = wave_shl:1 / wave_shr:1, 0x142 / 0x143 = row_bcast:15 / 31
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v, int old) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+
 // ------------------------------------------------------------------------------------------------
 // Field extraction.  Both return the index already multiplied by 128 (bits [7, 7+BITS)), ready to be
 // OR-ed into an LDS byte address (one entry row of a sub-table is 32 slots x 4 B = 128 B).

@@ -35,18 +35,20 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
   if (e1 > nnz) e1 = nnz;
   if (e0 >= e1) return;
 #ifdef SQLLM_ABLATION_BUILD
-  const int cabl = lin_or_abl_bits;  // 1 = skip the role, 2 = skip the flush, 4 = skip the accumulation
+  const int cabl = lin_or_abl_bits;  // 1 = skip the role, 2 = skip the flush, 4 = skip the accumulation, 8 = no x gathers
   if (cabl & 1) return;
 #endif
 
   // ---- round 1 ----
-  constexpr int EPT = kCsrChunk / T;  // non-zeros per thread: e0 + tid + T * i (coalesced)
+  constexpr int EPT = kCsrChunk / T;  // non-zeros per thread
+  static_assert(XTMODE || EPT == 2, "the lane-run accumulation below is written for two non-zeros per lane");
   int col[EPT];
   float val[EPT];
-  // element of (thread, i): interleaved over the workgroup, or -- transposed-vec mode -- EPT runs of 64
-  // that are consecutive within a wave (so that only a wave's first and last row are shared with its
-  // neighbours)
-  auto elem = [&](int i) { return XTMODE ? e0 + (tid >> 6) * (64 * EPT) + 64 * i + (tid & 63) : e0 + tid + T * i; };
+  // element of (thread, i): transposed-vec mode -- EPT runs of 64 that are consecutive within a wave (so that
+  // only a wave's first and last row are shared with its neighbours)
+  //  -- otherwise -- EPT consecutive non-zeros per lane (a wave holds 64 * EPT consecutive ones: the lane folds
+  // its own run serially, so ONE segmented scan per batch row serves the whole run)
+  auto elem = [&](int i) { return XTMODE ? e0 + (tid >> 6) * (64 * EPT) + 64 * i + (tid & 63) : e0 + EPT * tid + i; };
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
     int e = elem(i);
@@ -113,12 +115,10 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
     }
     lr[i] = (e < e1) ? lo : -1;
   }
-  // segment structure of each 64-lane run of non-zeros (fixed for all batch rows): bit d = the lane
-  // 2^d below belongs to the same row (take its partial sum in scan step d), bit 6 = last lane of
-  // its row segment
+  // (transposed-vec mode) segment structure of each 64-lane run of non-zeros: bit 6 = last lane of its row segment
   unsigned seg[EPT];
 #pragma unroll
-  for (int i = 0; i < EPT; ++i) {
+  for (int i = 0; i < (XTMODE ? EPT : 0); ++i) {
     const int lane = tid & 63;
     unsigned m = 0;
 #pragma unroll
@@ -199,42 +199,76 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
     }
   } else {
   const int nm1 = n - 1 > 0 ? n - 1 : 1;
+  // A wave holds 128 consecutive non-zeros, two per lane, i.e. a few whole or partial rows.  Per batch row: the
+  // lane folds its own two products (unless a row ends between them), ONE segmented inclusive scan across the
+  // lanes sums every lane's open segment (row shifts 1 / 2 / 4 / 8, then the row broadcasts 15 and 31 -- all
+  // DPP, no LDS traffic), and a row segment leaves from the lane that holds its last non-zero: at most two LDS
+  // adds per lane.  The structure is the same for every batch row and is worked out once:
+  //   take[d]  : scan step d adds the partial sum it is offered (the source lane's last row == this lane's;
+  //              rows are sorted, so everything in between is that row too)
+  //   bnd      : a row ends between the lane's two non-zeros (its first one then closes the segment that may
+  //              have come in from the lane below: flush_head, with that lane's sum if cont_prev)
+  //   flush_tail: the lane above starts another row (or there is none)
+  // (Before: non-zeros interleaved across the workgroup and one six-step ds_bpermute scan per non-zero and batch
+  // row -- at 8 rows 9 of the 12 us the sparse terms add to a 13B hybrid launch, profiles/r03_sparse_role_batch.txt.
+  // 64 LDS adds colliding on 2-3 addresses, the first version, execute one lane at a time: 17 of 49 us.)
+  const int rf = lr[0], rl = lr[1];
+  const bool bnd = rf != rl;
+  bool take[6];
+  take[0] = dpp_i32<0x111, 0xf>(rl, -2) == rl;
+  take[1] = dpp_i32<0x112, 0xf>(rl, -2) == rl;
+  take[2] = dpp_i32<0x114, 0xf>(rl, -2) == rl;
+  take[3] = dpp_i32<0x118, 0xf>(rl, -2) == rl;
+  take[4] = dpp_i32<0x142, 0xa>(rl, -2) == rl;
+  take[5] = dpp_i32<0x143, 0xc>(rl, -2) == rl;
+  // (every cross-lane read is a statement of its own, ahead of the logic: behind a short-circuit && it would run
+  // with the lanes that fail the first test switched off -- and a DPP read of a switched-off lane returns `old`)
+  const int prev_rl = dpp_i32<0x138, 0xf>(rl, -2), next_rf = dpp_i32<0x130, 0xf>(rf, -2);
+  const bool cont_prev = prev_rl == rf;
+  const bool flush_head = bnd & (rf >= 0);
+  const bool flush_tail = (rl >= 0) & (next_rf != rl);
   for (int bs = 0; bs < nb; bs += g) {
     const int gb = nb - bs < g ? nb - bs : g;
     if (in_lds && bs > 0) {
       for (int i = tid; i < n * gb; i += T) sacc[i] = 0.f;
       __syncthreads();
     }
+    // x of the group's rows for both non-zeros (unconditional loads: rows past the group re-read its last row)
+    float xv[EPT][BT];
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      float xv[BT];
+    for (int i = 0; i < EPT; ++i)
 #pragma unroll
-      for (int bb = 0; bb < BT; ++bb) {  // unconditional loads (rows past the group re-read its last row)
+      for (int bb = 0; bb < BT; ++bb) {
         const int bi = bs + (bb < gb ? bb : gb - 1);
-        xv[bb] = (float)x[(size_t)(b0 + bi) * K + col[i]];
-      }
-      if (bs == 0) xv[0] = xg[i];
-      // a wave holds 64 consecutive non-zeros, i.e. a few whole or partial rows: segmented
-      // inclusive scan by row across the lanes, then ONE add per row segment (from its last lane)
-      // instead of 64 adds that collide on 2-3 addresses -- LDS float atomics to one address are
-      // executed one lane at a time (measured: 17 of 49 us of a batch-8 13B hybrid launch).
-      const int r = lr[i];
-      const unsigned sm = seg[i];
+        xv[i][bb] = (bs == 0 && bb == 0) ? xg[i] : (float)x[(size_t)(b0 + bi) * K + col[i]];
 #ifdef SQLLM_ABLATION_BUILD
-      if (cabl & 4) continue;
+        if (cabl & 8) xv[i][bb] = 1.f + bb;  // measurement: no gathers
 #endif
+      }
+#ifdef SQLLM_ABLATION_BUILD
+    const bool skip_acc = cabl & 4;
+#else
+    constexpr bool skip_acc = false;
+#endif
+    if (!skip_acc) {
 #pragma unroll
       for (int bb = 0; bb < BT; ++bb) {
         if (bb < gb) {
-          float p = val[i] * xv[bb];
-#pragma unroll
-          for (int d = 0; d < 6; ++d) {
-            const float up = __shfl_up(p, 1 << d, 64);
-            if (sm & (1u << d)) p += up;
+          const float p0 = val[0] * xv[0][bb], p1 = val[1] * xv[1][bb];
+          float t = bnd ? p1 : p0 + p1;  // the lane's open (last) segment
+#define SQLLM_SCAN_STEP(D, CTRL, RM) { const float up = dpp_f32<CTRL, RM>(t); t += take[D] ? up : 0.f; }
+          SQLLM_SCAN_STEP(0, 0x111, 0xf) SQLLM_SCAN_STEP(1, 0x112, 0xf) SQLLM_SCAN_STEP(2, 0x114, 0xf)
+          SQLLM_SCAN_STEP(3, 0x118, 0xf) SQLLM_SCAN_STEP(4, 0x142, 0xa) SQLLM_SCAN_STEP(5, 0x143, 0xc)
+#undef SQLLM_SCAN_STEP
+          const float carry = dpp_f32<0x138, 0xf>(t);  // the lane below's inclusive sum
+          if (flush_head) {
+            const float h = p0 + (cont_prev ? carry : 0.f);
+            if (in_lds) atomicAdd(sacc + bb * n + rf, h);
+            else acc_add(y + (size_t)(b0 + bs + bb) * N + c_lo + rf, h);
           }
-          if ((sm & 64u) && r >= 0) {
-            if (in_lds) atomicAdd(sacc + bb * n + r, p);
-            else acc_add(y + (size_t)(b0 + bs + bb) * N + c_lo + r, p);
+          if (flush_tail) {
+            if (in_lds) atomicAdd(sacc + bb * n + rl, t);
+            else acc_add(y + (size_t)(b0 + bs + bb) * N + c_lo + rl, t);
           }
         }
       }
