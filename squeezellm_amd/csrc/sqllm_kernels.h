@@ -10,22 +10,28 @@
 #ifndef SQLLM_ABLATION_BUILD
 #if defined(SQLLM_PAIR3) || defined(SQLLM_PAIR3_NOCONFLICT) || defined(SQLLM_MFMA_VAR) || defined(SQLLM_MFMA_FAKE) || \
     defined(SQLLM_HALF_STAGES) || defined(SQLLM_WAVES) || defined(SQLLM_STREAM_RING) || defined(SQLLM_STREAM_WGCU) || \
-    defined(SQLLM_STREAM_PRO)
+    defined(SQLLM_STREAM_PRO) || defined(SQLLM_TOPX_ROWS) || defined(SQLLM_CSR_CHUNK)
 #error "kernel variant switches need -DSQLLM_ABLATION_BUILD (python -m squeezellm_amd.build --ablation)"
 #endif
 #endif
 #ifndef SQLLM_WAVES
 #define SQLLM_WAVES 8  // waves per workgroup (measurement builds: 4)
 #endif
+#ifndef SQLLM_CSR_CHUNK
+#define SQLLM_CSR_CHUNK 1024  // non-zeros per CSR workgroup (measurement builds: 2048)
+#endif
+#ifndef SQLLM_TOPX_ROWS
+#define SQLLM_TOPX_ROWS 256  // k's per top-X slab (measured 128 / 256 / 512: profiles/r03_csr_chunk_topx_slab.txt)
+#endif
 
 namespace sqllm {
 
 constexpr int kWaves = SQLLM_WAVES;          // waves per workgroup (512 threads)
 constexpr int kTileN = 64;         // output columns per dense tile = 16 lanes x 4 (one dwordx4 each)
-constexpr int kCsrChunk = 1024;    // non-zeros per CSR workgroup
+constexpr int kCsrChunk = SQLLM_CSR_CHUNK;  // non-zeros per CSR workgroup (a multiple of 1024: a lane holds a run of 2+)
 constexpr int kCsrSpanMax = 2048;  // CSR rows a chunk may span and still accumulate in LDS
 constexpr int kCsrXtSpan = 191;    // ... and still keep a 64-row tile of sums in LDS (wide batches, transposed vec)
-constexpr int kTopxRows = 128;     // k's per top-X slab
+constexpr int kTopxRows = SQLLM_TOPX_ROWS;  // k's per top-X slab (a multiple of 32)
 constexpr int kTopxLds = 1024;     // topX up to which slab sums are kept in LDS
 constexpr int kMaxBatchTile = 8;   // batch rows handled per weight pass
 constexpr int kMaxSlices = 120;    // K slices per column tile

@@ -41,7 +41,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
 
   // ---- round 1 ----
   constexpr int EPT = kCsrChunk / T;  // non-zeros per thread
-  static_assert(XTMODE || EPT == 2, "the lane-run accumulation below is written for two non-zeros per lane");
+  static_assert(EPT >= 2, "a lane holds a run of consecutive non-zeros");
   int col[EPT];
   float val[EPT];
   // element of (thread, i): transposed-vec mode -- EPT runs of 64 that are consecutive within a wave (so that
@@ -95,25 +95,37 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
   if (use_tile) for (int i = tid; i < 64 * TS; i += T) tile[i] = 0.f;
   __syncthreads();
 
-  // local row of each non-zero: largest i with rows[c_lo + i] <= e
+  // local row of each non-zero: largest i with rows[c_lo + i] <= e.  The searches of a lane's non-zeros advance
+  // in lockstep through ONE loop of a fixed, workgroup-uniform trip count (their LDS reads are independent and
+  // overlap; once a search has converged, mid == lo and the step is a no-op): a while loop per non-zero is a
+  // chain of 6-7 dependent LDS round trips EACH, 0.6-0.7 us of the workgroup's life per non-zero of a lane
+  // (measured through the chunk size: 4 per lane added 1.3 us to the o_proj launch, profiles/r03_csr_chunk_topx_slab.txt)
   int lr[EPT];
+  {
+    int lo[EPT], hi[EPT];
+    const int H = n - 1 > 1 ? n - 1 : 1;  // answer in [0, H): rows[c_lo + n - 1] > e by construction
 #pragma unroll
-  for (int i = 0; i < EPT; ++i) {
-    const int e = elem(i);
-    int lo = 0, hi = n - 1;  // answer in [lo, hi): rows[c_lo + n - 1] > e by construction
-    if (hi < 1) hi = 1;
+    for (int i = 0; i < EPT; ++i) { lo[i] = 0; hi[i] = H; }
     if (in_lds) {
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (srows[mid] <= e) lo = mid; else hi = mid;
+      const int iters = H > 1 ? 32 - __builtin_clz(H - 1) : 0;
+      for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+          const int mid = (lo[i] + hi[i]) >> 1;
+          if (srows[mid] <= elem(i)) lo[i] = mid; else hi[i] = mid;
+        }
       }
     } else {  // a chunk spanning > kCsrSpanMax rows (extremely sparse region): search in global memory
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (rows[c_lo + mid] <= e) lo = mid; else hi = mid;
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        while (hi[i] - lo[i] > 1) {
+          const int mid = (lo[i] + hi[i]) >> 1;
+          if (rows[c_lo + mid] <= elem(i)) lo[i] = mid; else hi[i] = mid;
+        }
       }
     }
-    lr[i] = (e < e1) ? lo : -1;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) lr[i] = (elem(i) < e1) ? lo[i] : -1;
   }
   // (transposed-vec mode) segment structure of each 64-lane run of non-zeros: bit 6 = last lane of its row segment
   unsigned seg[EPT];
@@ -199,21 +211,34 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
     }
   } else {
   const int nm1 = n - 1 > 0 ? n - 1 : 1;
-  // A wave holds 128 consecutive non-zeros, two per lane, i.e. a few whole or partial rows.  Per batch row: the
-  // lane folds its own two products (unless a row ends between them), ONE segmented inclusive scan across the
-  // lanes sums every lane's open segment (row shifts 1 / 2 / 4 / 8, then the row broadcasts 15 and 31 -- all
-  // DPP, no LDS traffic), and a row segment leaves from the lane that holds its last non-zero: at most two LDS
-  // adds per lane.  The structure is the same for every batch row and is worked out once:
-  //   take[d]  : scan step d adds the partial sum it is offered (the source lane's last row == this lane's;
-  //              rows are sorted, so everything in between is that row too)
-  //   bnd      : a row ends between the lane's two non-zeros (its first one then closes the segment that may
-  //              have come in from the lane below: flush_head, with that lane's sum if cont_prev)
+  // A wave holds 64 * EPT consecutive non-zeros, EPT per lane, i.e. a few whole or partial rows.  Per batch row:
+  // the lane folds its own products serially (q[i] = running sum of the row segment that non-zero i belongs to),
+  // ONE segmented inclusive scan across the lanes sums every lane's open (last) segment (row shifts 1 / 2 / 4 / 8,
+  // then the row broadcasts 15 and 31 -- all DPP, no LDS traffic), and a row segment leaves from the lane that
+  // holds its last non-zero.  The structure is the same for every batch row and is worked out once:
+  //   b[i]      : a row ends between the lane's non-zeros i and i + 1
+  //   take[d]   : scan step d adds the partial sum it is offered (the source lane's last row == this lane's;
+  //               rows are sorted, so everything in between is that row too)
+  //   flush_head: the lane holds a row end; its FIRST segment then closes what may have come in from the lane
+  //               below (that lane's inclusive sum, if cont_prev)
+  //   mid[i]    : a segment that starts and ends inside the lane (rows of 1-2 non-zeros), closing at i
   //   flush_tail: the lane above starts another row (or there is none)
   // (Before: non-zeros interleaved across the workgroup and one six-step ds_bpermute scan per non-zero and batch
-  // row -- at 8 rows 9 of the 12 us the sparse terms add to a 13B hybrid launch, profiles/r03_sparse_role_batch.txt.
-  // 64 LDS adds colliding on 2-3 addresses, the first version, execute one lane at a time: 17 of 49 us.)
-  const int rf = lr[0], rl = lr[1];
+  // row -- profiles/r03_sparse_role_batch.txt, r03_ab_csr_lane_runs.txt.  64 LDS adds colliding on 2-3
+  // addresses, the first version, execute one lane at a time: 17 of 49 us; with the 2-3 lanes that are active
+  // here an LDS float add costs 3-4 ns, profiles/r03_lds_atomic_sparse.txt.)
+  const int rf = lr[0], rl = lr[EPT - 1];
   const bool bnd = rf != rl;
+  bool b[EPT - 1], mid[EPT - 1];
+  {
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < EPT - 1; ++i) {
+      b[i] = lr[i] != lr[i + 1];
+      mid[i] = b[i] & any & (lr[i] >= 0);
+      any |= b[i];
+    }
+  }
   bool take[6];
   take[0] = dpp_i32<0x111, 0xf>(rl, -2) == rl;
   take[1] = dpp_i32<0x112, 0xf>(rl, -2) == rl;
@@ -254,17 +279,30 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
 #pragma unroll
       for (int bb = 0; bb < BT; ++bb) {
         if (bb < gb) {
-          const float p0 = val[0] * xv[0][bb], p1 = val[1] * xv[1][bb];
-          float t = bnd ? p1 : p0 + p1;  // the lane's open (last) segment
+          float q[EPT];
+          q[0] = val[0] * xv[0][bb];
+#pragma unroll
+          for (int i = 1; i < EPT; ++i) q[i] = __builtin_fmaf(val[i], xv[i][bb], b[i - 1] ? 0.f : q[i - 1]);
+          float head = q[EPT - 1];
+#pragma unroll
+          for (int i = EPT - 2; i >= 0; --i) head = b[i] ? q[i] : head;  // the first row end wins
+          float t = q[EPT - 1];  // the lane's open (last) segment
 #define SQLLM_SCAN_STEP(D, CTRL, RM) { const float up = dpp_f32<CTRL, RM>(t); t += take[D] ? up : 0.f; }
           SQLLM_SCAN_STEP(0, 0x111, 0xf) SQLLM_SCAN_STEP(1, 0x112, 0xf) SQLLM_SCAN_STEP(2, 0x114, 0xf)
           SQLLM_SCAN_STEP(3, 0x118, 0xf) SQLLM_SCAN_STEP(4, 0x142, 0xa) SQLLM_SCAN_STEP(5, 0x143, 0xc)
 #undef SQLLM_SCAN_STEP
           const float carry = dpp_f32<0x138, 0xf>(t);  // the lane below's inclusive sum
           if (flush_head) {
-            const float h = p0 + (cont_prev ? carry : 0.f);
+            const float h = head + (cont_prev ? carry : 0.f);
             if (in_lds) atomicAdd(sacc + bb * n + rf, h);
             else acc_add(y + (size_t)(b0 + bs + bb) * N + c_lo + rf, h);
+          }
+#pragma unroll
+          for (int i = 1; i < EPT - 1; ++i) {
+            if (mid[i]) {
+              if (in_lds) atomicAdd(sacc + bb * n + lr[i], q[i]);
+              else acc_add(y + (size_t)(b0 + bs + bb) * N + c_lo + lr[i], q[i]);
+            }
           }
           if (flush_tail) {
             if (in_lds) atomicAdd(sacc + bb * n + rl, t);
@@ -338,13 +376,14 @@ __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
     // register, two cross-lane adds fold the wave's 4 lane rows, the 8 waves meet in LDS through
     // plain stores.  No LDS atomics (64 lanes on 10 addresses execute one lane at a time: that and
     // two more barriers cost 0.6-0.9 us on the grouped 7B launches), one barrier per batch row.
-    static_assert(T == 512, "32 lane rows x 4 k's cover the 128-k slab");
+    static_assert(T == 512 && kTopxRows % 32 == 0, "32 lane rows x NI k's cover the slab");
+    constexpr int NI = kTopxRows / 32;
     const int c = tid & 15, krow = tid >> 4;  // krow 0..31
     const int lane = tid & 63, wave = tid >> 6;
     const bool live = c < topX;
-    float frv[4];
+    float frv[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       int k = k0 + krow + 32 * i;
       if (k > k1 - 1) k = k1 - 1;  // clamped re-read, masked below
       frv[i] = live ? full_rows[(size_t)k * topX + c] : 0.f;
@@ -354,7 +393,7 @@ __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
       const XT* xb = x + (size_t)(b0 + b) * K;
       float p = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NI; ++i) {
         const int k = k0 + krow + 32 * i;
         p = __builtin_fmaf(frv[i], k < k1 ? (float)xb[k] : 0.f, p);
       }
