@@ -70,7 +70,7 @@ def test_plan_geometry():
     # every unit is covered exactly once
     assert p["k_slices"] * p["groups_per_wave"] >= 4096 // 8 > (p["k_slices"] - 1) * p["groups_per_wave"]
     p3 = _lib.plan_query(3, 11008, 4096, nnz=202_899, topX=10)
-    assert p3["csr_blocks"] == -(-202_899 // 1024) and p3["topx_blocks"] == 11008 // 128
+    assert p3["csr_blocks"] == -(-202_899 // 1024) and p3["topx_blocks"] == 11008 // 256  # slabs of 256 rows
     assert p3["grid_x"] >= p3["dense_blocks"] + p3["csr_blocks"] + p3["topx_blocks"]
     assert (p3["grid_x"] - p3["dense_blocks"]) % 8 == 0  # dense ids stay XCD-aligned
     assert _lib.plan_query(4, 4096, 4096, batch=3)["grid_y"] == 1
