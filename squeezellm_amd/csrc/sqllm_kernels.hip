@@ -522,7 +522,14 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
                                          d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds, sg, LIN ? &ga.seg[s] : nullptr);
   } else if (sp >= 0 && sp < gm.csr_blocks) {
     csr_role<T, BT, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds,
-                        LIN ? &ga.seg[s] : nullptr, gm.sparse_last >> 1);
+                        LIN ? &ga.seg[s] : nullptr, gm.sparse_last >> 1, nullptr, 0,
+#ifdef SQLLM_ABLATION_BUILD
+                        (!LIN && sg.bias) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(sg.bias)) +
+                                                8ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y) : nullptr
+#else
+                        nullptr
+#endif
+    );
   } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
     // (never taken when the plan folds the top-X rows into the dense tiles)
     topx_role<T, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, b0, nb, sp - gm.csr_blocks, lds);

@@ -27,7 +27,8 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
                                          const int* __restrict__ rows, const int* __restrict__ cols,
                                          const float* __restrict__ vals, int nnz, int K, int N, int b0,
                                          int nb, int chunk, float* lds, const Segment* lin, int lin_or_abl_bits = 0,
-                                         const float* __restrict__ xT = nullptr, int Bp = 0) {
+                                         const float* __restrict__ xT = nullptr, int Bp = 0,
+                                         unsigned long long* tl = nullptr) {
   constexpr bool LIN = sizeof(AT) == 8;
   const int tid = threadIdx.x;
   const int e0 = chunk * kCsrChunk;
@@ -37,6 +38,11 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
 #ifdef SQLLM_ABLATION_BUILD
   const int cabl = lin_or_abl_bits;  // 1 = skip the role, 2 = skip the flush, 4 = skip the accumulation, 8 = no x gathers
   if (cabl & 1) return;
+  // timeline probe (tools/timeline.py): the entry stamp is stored NEGATED, which tells a chunk workgroup from a dense one
+  if (tl && tid == 0) tl[0] = 0ull - __builtin_amdgcn_s_memrealtime();
+#define SQLLM_CSR_STAMP(I) if (tl && tid == 0) tl[I] = __builtin_amdgcn_s_memrealtime();
+#else
+#define SQLLM_CSR_STAMP(I)
 #endif
 
   // ---- round 1 ----
@@ -56,6 +62,11 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
     col[i] = cols[e];
     val[i] = vals[e];
   }
+  // The span of row pointers the chunk needs, rows[c_lo .. c_hi] with rows[c_lo] <= e0 and rows[c_hi] > e1 - 1: one
+  // sampled probe of `rows` per thread and two block-wide counts.  (A per-chunk table of these spans, written once
+  // per matrix and handed in through the op descriptor, was built and measured: the chunk workgroups live 0.5-0.9 us
+  // shorter -- their row pointers go out in the first round -- and the 7B s45 launches get 1-2.5 % SLOWER, the
+  // earlier gathers landing in the dense workgroups' load phase; profiles/r03_timeline_csr.txt.  Not kept.)
   const int S = (N + T) / T;  // sample stride: T samples cover rows[0 .. N]
   const int si = tid * S;
   const int probe = rows[si < N ? si : N];
@@ -65,6 +76,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
   const int c_lo = (cnt_lo > 0 ? cnt_lo - 1 : 0) * S;  // rows[c_lo] <= e0
   int c_hi = cnt_hi * S;                                // rows[c_hi] > e1 - 1 (or the end)
   if (c_hi > N) c_hi = N;
+  SQLLM_CSR_STAMP(1)  // round 1 (cols / vals / probes) has landed, both counts done
   const int n = c_hi - c_lo + 1;  // staged row pointers rows[c_lo .. c_hi]; candidate rows: n - 1
   const bool in_lds = n <= kCsrSpanMax;
 
@@ -94,6 +106,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
   float* tile = lds + kCsrSpanMax;
   if (use_tile) for (int i = tid; i < 64 * TS; i += T) tile[i] = 0.f;
   __syncthreads();
+  SQLLM_CSR_STAMP(2)  // row pointers staged
 
   // local row of each non-zero: largest i with rows[c_lo + i] <= e.  The searches of a lane's non-zeros advance
   // in lockstep through ONE loop of a fixed, workgroup-uniform trip count (their LDS reads are independent and
@@ -127,6 +140,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
 #pragma unroll
     for (int i = 0; i < EPT; ++i) lr[i] = (elem(i) < e1) ? lo[i] : -1;
   }
+  SQLLM_CSR_STAMP(3)  // rows found
   // (transposed-vec mode) segment structure of each 64-lane run of non-zeros: bit 6 = last lane of its row segment
   unsigned seg[EPT];
 #pragma unroll
@@ -313,6 +327,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
     }
     if (in_lds) {
       __syncthreads();
+      SQLLM_CSR_STAMP(4)  // x gathered, products scanned, row sums in LDS
 #ifdef SQLLM_ABLATION_BUILD
       if (cabl & 2) continue;
 #endif
@@ -334,6 +349,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
           if (sum != 0.f) acc_add(y + at, sum);
         }
       }
+      SQLLM_CSR_STAMP(5)  // atomics issued
       __syncthreads();
     } else if constexpr (LIN) {
       // (g == 1 here) the values went in uncounted, one add per non-zero; once they are
@@ -433,5 +449,7 @@ __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
     }
   }
 }
+
+#undef SQLLM_CSR_STAMP
 
 }  // namespace sqllm

@@ -54,11 +54,19 @@ def main():
         torch.cuda.synchronize()
     lib.sqllm_debug_set_timeline(None)
     t = buf.cpu().numpy().astype(np.float64) / 100.0  # 100 MHz ticks -> us
-    rows = []
+    raw = buf.cpu().numpy()
+    rows, crows = [], []
     for gi in range(2, len(seq.groups)):  # skip the first two (cold)
         g = t[gi]
+        c = raw[gi][raw[gi][:, 0] < 0].astype(np.float64) / 100.0  # CSR chunk workgroups stamp their entry negated
         g = g[g[:, 0] > 0]  # dense workgroups only
         t0 = g[:, 0].min()
+        if len(c):
+            c[:, 0] = -c[:, 0]
+            t0 = min(t0, c[:, 0].min())
+            d = np.diff(c[:, :6], axis=1)
+            crows.append([np.percentile(c[:, 0] - t0, 50)] + [np.percentile(d[:, i], 50) for i in range(5)] +
+                         [np.percentile(c[:, 5] - c[:, 0], 50), (c[:, 5] - t0).max(), len(c)])
         rows.append([np.percentile(g[:, 0] - t0, 50), (g[:, 0] - t0).max(), np.percentile(g[:, 1] - g[:, 0], 50),
                      np.percentile(g[:, 2] - g[:, 1], 50), np.percentile(g[:, 3] - g[:, 2], 50),
                      np.percentile(g[:, 3] - t0, 50), (g[:, 3] - t0).max(), (g[:, 4:8].max(axis=1) - g[:, 2]).mean(), len(g)])
@@ -69,6 +77,11 @@ def main():
     print(f"  barrier -> wave 0 done decoding         : median {r[3]:.2f} us   (slowest of waves 0-3 finishes {r[7]:+.2f} us later)")
     print(f"  wave 0 decode end -> atomics issued     : median {r[4]:.2f} us")
     print(f"  first entry -> atomics issued           : median {r[5]:.2f} us, last workgroup {r[6]:.2f} us")
+    if crows:
+        c = np.array(crows).mean(axis=0)
+        print(f"  CSR chunk workgroups ({int(c[8])}): entry {c[0]:.2f} us after the first workgroup; entry -> round 1 landed + counts {c[1]:.2f}, "
+              f"-> row pointers staged {c[2]:.2f}, -> rows found {c[3]:.2f}, -> x gathered + sums in LDS {c[4]:.2f}, -> atomics issued {c[5]:.2f}; "
+              f"life {c[6]:.2f} us (median), last one done at {c[7]:.2f} us")
 
 
 if __name__ == "__main__":
