@@ -38,6 +38,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
 #ifdef SQLLM_ABLATION_BUILD
   const int cabl = lin_or_abl_bits;  // 1 = skip the role, 2 = skip the flush, 4 = skip the accumulation, 8 = no x gathers
   if (cabl & 1) return;
+  for (int d = cabl >> 4; d > 0; --d) __builtin_amdgcn_s_sleep(8);  // measurement: hold the role back by (cabl >> 4) x ~0.2 us
   // timeline probe (tools/timeline.py): the entry stamp is stored NEGATED, which tells a chunk workgroup from a dense one
   if (tl && tid == 0) tl[0] = 0ull - __builtin_amdgcn_s_memrealtime();
 #define SQLLM_CSR_STAMP(I) if (tl && tid == 0) tl[I] = __builtin_amdgcn_s_memrealtime();
