@@ -21,6 +21,7 @@ struct Knobs {
   std::atomic<int> groups_per_wave{0};
   std::atomic<int> cu_count{0};
   std::atomic<int> ablate{0};
+  std::atomic<int> lds_pad{0};  // measurement builds: unused dynamic LDS per workgroup, bytes
   std::atomic<int> sparse_last{0};
   std::atomic<int> ablate_csr{0};
   // Routing of the *_batched operators by batch size (0 = the measured defaults, which depend on the bit width:
@@ -396,6 +397,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "pair4")) { knobs().pair4.store(value > 1 ? -1 : value); return SQLLM_OK; }    // 0 off, 1 on, 2 default (off)
   if (!strcmp(name, "pair4_min_mb")) { knobs().pair4_min_mb.store(value); return SQLLM_OK; }
   if (!strcmp(name, "ablate")) { knobs().ablate.store(value); return SQLLM_OK; }
+  if (!strcmp(name, "lds_pad")) { knobs().lds_pad.store(value); return SQLLM_OK; }
   if (!strcmp(name, "ablate_csr")) { knobs().ablate_csr.store(value); return SQLLM_OK; }
 #endif
   return SQLLM_E_OPTION;
@@ -605,6 +607,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
   a.ev_start = e0;
   a.ev_stop = e1;
   a.ablate = knobs().ablate.load(std::memory_order_relaxed);
+  a.lds_pad = knobs().lds_pad.load(std::memory_order_relaxed);
   a.x = ops[0].vec;
   a.ga.n_seg = n;
   int block = 0;

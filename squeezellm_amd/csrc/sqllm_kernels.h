@@ -101,6 +101,7 @@ struct LaunchArgs {
   hipEvent_t ev_start = nullptr;  // optional: recorded at this kernel's begin / end (profiling aid)
   hipEvent_t ev_stop = nullptr;
   int ablate = 0;  // measurement builds only (SQLLM_ABLATION_BUILD)
+  int lds_pad = 0;  // measurement builds only: bytes of unused dynamic LDS per workgroup (caps the workgroups per CU)
   const float* xT = nullptr;  // wide-batch launches: transposed copy of x ([K, Bp]) for the CSR role, or null
   int Bp = 0;
 };

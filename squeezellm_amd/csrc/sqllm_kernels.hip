@@ -1276,9 +1276,9 @@ static hipError_t launch_inst(const LaunchArgs& a, hipStream_t stream) {
   auto kern = sqllm_fused_matvec<BITS, BT, WAVES, ABL, LIN>;
   if (a.ev_start || a.ev_stop) {
     // same kernel, with the dispatch's own begin/end timestamps exposed through two events
-    hipExtLaunchKernelGGL(kern, grid, dim3(WAVES * 64), 0, stream, a.ev_start, a.ev_stop, 0, a.x, a.ga);
+    hipExtLaunchKernelGGL(kern, grid, dim3(WAVES * 64), a.lds_pad, stream, a.ev_start, a.ev_stop, 0, a.x, a.ga);
   } else {
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), 0, stream, a.x, a.ga);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), a.lds_pad, stream, a.x, a.ga);
   }
   return hipGetLastError();
 }
