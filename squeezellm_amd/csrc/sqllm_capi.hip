@@ -541,6 +541,9 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
         if (sparse) {
           sqllm::LaunchArgs as = a;
           as.ev_stop = nullptr;
+#ifdef SQLLM_ABLATION_BUILD
+          as.ga.seg[0].bias = static_cast<const float*>(knobs().timeline.load(std::memory_order_relaxed));  // timeline probe (tools/timeline.py --batch)
+#endif
           rc = static_cast<int>(sqllm::launch_batched_sparse(as, static_cast<hipStream_t>(stream)));
           if (rc != SQLLM_OK) return rc;
           a.ev_start = nullptr;

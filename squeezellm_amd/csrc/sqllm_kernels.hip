@@ -882,7 +882,7 @@ template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 sqllm_sparse_batched(const float* x, const GroupArgs ga, const float* xT, int Bp) {
   constexpr int T = WAVES * 64;
-  __shared__ __attribute__((aligned(16))) float lds[cmax(kCsrSpanMax + cmax(kCsrSpanMax, 64 * (kCsrXtSpan + 1)), kTopxLds)];
+  __shared__ __attribute__((aligned(16))) float lds[cmax(kCsrSpanMax + cmax(kCsrSpanMax, 64 * (kCsrXtSpan + 1) + 3 * kCsrChunk), kTopxLds)];
   const Segment sg = ga.seg[0];  // the whole descriptor in one round of scalar loads (see sqllm_fused_matvec)
   asm volatile("" ::SQLLM_SEG_OPERANDS(sg), "s"(x));
   __builtin_amdgcn_sched_barrier(0);
@@ -893,7 +893,12 @@ sqllm_sparse_batched(const float* x, const GroupArgs ga, const float* xT, int Bp
   if (rows_here > 64) rows_here = 64;
   if (sp < gm.csr_blocks) {
     if (xT) {
-      csr_role<T, 1, float, float, true>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, m0, rows_here, sp, lds, nullptr, 0, xT, Bp);
+      csr_role<T, 1, float, float, true>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, m0, rows_here, sp, lds, nullptr, 0, xT, Bp
+#ifdef SQLLM_ABLATION_BUILD
+                                         , sg.bias ? reinterpret_cast<unsigned long long*>(const_cast<float*>(sg.bias)) +
+                                                         8ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y) : nullptr
+#endif
+      );
     } else {
       constexpr int CBT = 32;  // every group of rows costs the chunk a zero / gather / flush round with its barriers
       for (int bb = 0; bb < rows_here; bb += CBT) {

@@ -7,6 +7,40 @@
 
 namespace sqllm {
 
+// One wave's share of a chunk in transposed-vec mode at 32 rows or fewer (see csr_role): st = the wave's WN
+// non-zeros in LDS as [column | value bits | local row] planes kCsrChunk apart; R rows per pass -> 64 / R lane
+// groups, each walking a contiguous run of WN * R / 64 non-zeros; row sums go to tile[row][local column] with an
+// LDS add each (1.25 ns per active lane -- cheaper than the code a plain-store variant would add to every step).
+template <int R, int WN>
+__device__ __forceinline__ void xt_walk(const int* st, const float* __restrict__ xT, int Bp, int b0, int nb, float* tile, int TS, int lane) {
+  constexpr int G = 64 / R, L = WN / G;
+  constexpr int U = L < 32 ? L : 32;  // loads in flight per lane: the role is latency-bound
+  const int bl = lane % R;
+  const int base = (lane / R) * L;
+  const float* xl = xT + (b0 + (bl < nb ? bl : 0));
+  float* trow = tile + bl * TS;
+  float acc = 0.f;
+#pragma unroll 1
+  for (int s0 = 0; s0 < L; s0 += U) {
+    if (__builtin_amdgcn_readfirstlane(st[2 * kCsrChunk + s0]) < 0) break;  // (valid non-zeros are a prefix: group 0 has run out, so have all)
+    float xv[U];
+    int rr[U + 1];  // local rows, read before the loop below: its LDS adds would otherwise force every one to be re-read
+#pragma unroll
+    for (int u = 0; u < U; ++u) xv[u] = xl[(size_t)st[base + s0 + u] * Bp];  // (columns past the end are clamped re-reads, their values 0)
+#pragma unroll
+    for (int u = 0; u < U; ++u) rr[u] = st[2 * kCsrChunk + base + s0 + u];
+    rr[U] = s0 + U == L ? -2 : st[2 * kCsrChunk + base + s0 + U];  // the run ends: whatever is open leaves
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc = __builtin_fmaf(__builtin_bit_cast(float, st[kCsrChunk + base + s0 + u]), xv[u], acc);
+      if (rr[u] != rr[u + 1]) {
+        if (rr[u] >= 0) atomicAdd(trow + rr[u], acc);
+        acc = 0.f;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // CSR role: one workgroup per chunk of kCsrChunk consecutive non-zeros (balanced by nnz, so a few
 // very long rows cost nothing extra -- the reference walks one row per thread serially,
@@ -105,7 +139,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
   const bool use_tile = XTMODE && in_lds && n <= kCsrXtSpan;
   const int TS = n | 1;
   float* tile = lds + kCsrSpanMax;
-  if (use_tile) for (int i = tid; i < 64 * TS; i += T) tile[i] = 0.f;
+  if (use_tile) for (int i = tid; i < (nb <= 16 ? 16 : nb <= 32 ? 32 : 64) * TS; i += T) tile[i] = 0.f;  // (the rows of this pass's lane groups)
   __syncthreads();
   SQLLM_CSR_STAMP(2)  // row pointers staged
 
@@ -142,79 +176,85 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
     for (int i = 0; i < EPT; ++i) lr[i] = (elem(i) < e1) ? lo[i] : -1;
   }
   SQLLM_CSR_STAMP(3)  // rows found
-  // (transposed-vec mode) segment structure of each 64-lane run of non-zeros: bit 6 = last lane of its row segment
-  unsigned seg[EPT];
-#pragma unroll
-  for (int i = 0; i < (XTMODE ? EPT : 0); ++i) {
-    const int lane = tid & 63;
-    unsigned m = 0;
-#pragma unroll
-    for (int d = 0; d < 6; ++d) {
-      const int below = __shfl_up(lr[i], 1 << d, 64);
-      if (lane >= (1 << d) && below == lr[i]) m |= 1u << d;
-    }
-    const int above = __shfl_down(lr[i], 1, 64);
-    if (lane == 63 || above != lr[i]) m |= 64u;
-    seg[i] = m;
-  }
-
   if constexpr (XTMODE) {
-    // Wide batches with a TRANSPOSED copy of vec (xT[k][row], written by sqllm_transpose_vec just
-    // before this launch): lane = batch row.  A wave walks its 64 * EPT consecutive non-zeros one
-    // at a time -- column, value and row come out of the owning lane with v_readlane, so control flow
-    // and addresses are scalar -- and every lane loads ITS row's element of xT[k] (one coalesced
-    // read per non-zero instead of one gather per row, 4 K bytes apart) and multiplies.  At the last
-    // non-zero of a row the lanes park their sums in tile[row][column]: a plain store, or an LDS add
-    // for the wave's first and last row (which the neighbouring waves may hold parts of).  The tile
-    // leaves with the lanes along the COLUMNS: coalesced atomics (lanes along the rows would hit
-    // one cache line each: measured 2.1 ms of a 4.6 ms launch at 2048 rows).
+    // Wide batches with a TRANSPOSED copy of vec (xT[k][row], written by sqllm_transpose_vec just before this
+    // launch): lane = batch row, so a non-zero costs ONE coalesced read of xT[k] for all the rows instead of one
+    // gather per row, 4 K bytes apart.  A pass of at most 16 / 32 rows splits the wave into G = 4 / 2 lane groups,
+    // and each group walks its own run of the wave's non-zeros one at a time -- G non-zeros per step.  (With every lane a batch row whatever the batch, 9-16
+    // rows paid 128 serial steps per wave in four latency-bound batches of loads with 48 of 64 lanes idle: the
+    // sparse launch of a 16-row 13B op took 17 us; profiles/r03_wide_sparse_groups.txt.)  Columns, values and
+    // local rows reach the groups through LDS (staged by the lanes that loaded them; same-wave traffic, in
+    // order, no barrier).  At the last non-zero of a row the lanes park their sums in tile[row][column]: a
+    // plain store, or an LDS add for a group's first row and for whatever it holds at the end of its run
+    // (which the neighbouring groups / waves may hold parts of).  The tile leaves with the lanes along the
+    // COLUMNS: coalesced atomics (lanes along the rows would hit one cache line each: measured 2.1 ms of a
+    // 4.6 ms launch at 2048 rows).
+    constexpr int WN = 64 * EPT;  // non-zeros per wave
     const int lane = tid & 63;
-    const bool row_ok = lane < nb;
-    const float* xl = xT + (b0 + (row_ok ? lane : 0));
-    unsigned long long ends[EPT], valid[EPT];
-    int n_valid = 0;
+    int* st = reinterpret_cast<int*>(lds + kCsrSpanMax + 64 * (kCsrXtSpan + 1)) + (tid >> 6) * WN;  // [3][kCsrChunk]
+    if (nb <= 32 && use_tile) {
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      ends[i] = __ballot((seg[i] & 64u) && lr[i] >= 0);
-      valid[i] = __ballot(lr[i] >= 0);
-      n_valid += __builtin_popcountll(valid[i]);
+      for (int i = 0; i < EPT; ++i) {
+        st[64 * i + lane] = col[i];
+        st[kCsrChunk + 64 * i + lane] = lr[i] >= 0 ? __builtin_bit_cast(int, val[i]) : 0;
+        st[2 * kCsrChunk + 64 * i + lane] = lr[i];
+      }
     }
+    float* yf = reinterpret_cast<float*>(y);
+    if (nb <= 16 && use_tile) xt_walk<16, WN>(st, xT, Bp, b0, nb, tile, TS, lane);
+    else if (nb <= 32 && use_tile) xt_walk<32, WN>(st, xT, Bp, b0, nb, tile, TS, lane);
+    else {
+      // 33-64 rows (or a chunk spanning too many rows for the tile): one group, every lane a batch row.  Column, value and row come out of the owning lane with
+      // v_readlane, so control flow and addresses are scalar (2 % faster at 2048 rows than the walk through LDS).
+      const bool row_ok = lane < nb;
+      const float* xl = xT + (b0 + (row_ok ? lane : 0));
+      unsigned long long ends[EPT], valid[EPT];
+      int n_valid = 0;
 #pragma unroll
-    for (int i = 0; i + 1 < EPT; ++i)  // a row that runs on into the next run keeps its sum in the register
-      if ((valid[i + 1] & 1ull) && __builtin_amdgcn_readlane(lr[i], 63) == __builtin_amdgcn_readlane(lr[i + 1], 0)) ends[i] &= ~(1ull << 63);
-    float acc = 0.f;
-    bool first_seg = true;
+      for (int i = 0; i < EPT; ++i) {
+        const int above = dpp_i32<0x130, 0xf>(lr[i], -2);  // the lane above's row (lane 63: none)
+        ends[i] = __ballot(above != lr[i] && lr[i] >= 0);
+        valid[i] = __ballot(lr[i] >= 0);
+        n_valid += __builtin_popcountll(valid[i]);
+      }
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      constexpr int U = 32;  // loads in flight per wave: the role is latency-bound (a chunk is 1-2 workgroups per CU)
-      for (int j0 = 0; j0 < 64; j0 += U) {
-        if (((valid[i] >> j0) & 1ull) == 0) break;  // (valid lanes are a prefix)
-        float xv[U];
+      for (int i = 0; i + 1 < EPT; ++i)  // a row that runs on into the next run keeps its sum in the register
+        if ((valid[i + 1] & 1ull) && __builtin_amdgcn_readlane(lr[i], 63) == __builtin_amdgcn_readlane(lr[i + 1], 0)) ends[i] &= ~(1ull << 63);
+      float acc = 0.f;
+      bool first_seg = true;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int k = __builtin_amdgcn_readlane(col[i], j0 + u);
-          xv[u] = xl[(size_t)k * Bp];
-        }
+      for (int i = 0; i < EPT; ++i) {
+        constexpr int U = 32;  // loads in flight per wave: the role is latency-bound (a chunk is 1-2 workgroups per CU)
+        for (int j0 = 0; j0 < 64; j0 += U) {
+          if (((valid[i] >> j0) & 1ull) == 0) break;  // (valid lanes are a prefix)
+          float xv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int j = j0 + u;
-          const float v = ((valid[i] >> j) & 1ull) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val[i]), j)) : 0.f;
-          acc = __builtin_fmaf(v, xv[u], acc);
-          if ((ends[i] >> j) & 1ull) {
-            const int r = __builtin_amdgcn_readlane(lr[i], j);
-            if (use_tile) {
-              float* slot = tile + lane * TS + r;
-              if (first_seg || 64 * i + j == n_valid - 1) atomicAdd(slot, acc);  // LDS float atomic: lane by lane, twice per wave
-              else *slot = acc;
-            } else if (row_ok) {
-              acc_add(reinterpret_cast<float*>(y) + (size_t)(b0 + lane) * N + c_lo + r, acc);
+          for (int u = 0; u < U; ++u) {
+            const int k = __builtin_amdgcn_readlane(col[i], j0 + u);
+            xv[u] = xl[(size_t)k * Bp];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int j = j0 + u;
+            const float v = ((valid[i] >> j) & 1ull) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val[i]), j)) : 0.f;
+            acc = __builtin_fmaf(v, xv[u], acc);
+            if ((ends[i] >> j) & 1ull) {
+              const int r = __builtin_amdgcn_readlane(lr[i], j);
+              if (use_tile) {
+                float* slot = tile + lane * TS + r;
+                if (first_seg || 64 * i + j == n_valid - 1) atomicAdd(slot, acc);  // the wave's first and last row: shared with its neighbours
+                else *slot = acc;
+              } else if (row_ok) {
+                acc_add(yf + (size_t)(b0 + lane) * N + c_lo + r, acc);
+              }
+              first_seg = false;
+              acc = 0.f;
             }
-            first_seg = false;
-            acc = 0.f;
           }
         }
       }
     }
+    SQLLM_CSR_STAMP(4)  // this wave's non-zeros walked
     if (use_tile) {
       __syncthreads();
       const int nm1 = n - 1;
@@ -224,6 +264,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
         if (sum != 0.f) acc_add(reinterpret_cast<float*>(y) + (size_t)(b0 + b) * N + c_lo + r, sum);
       }
     }
+    SQLLM_CSR_STAMP(5)  // atomics issued
   } else {
   const int nm1 = n - 1 > 0 ? n - 1 : 1;
   // A wave holds 64 * EPT consecutive non-zeros, EPT per lane, i.e. a few whole or partial rows.  Per batch row:

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--sparse", type=float, default=0.0)
     ap.add_argument("--topx", type=int, default=0)
     ap.add_argument("--copies", type=int, default=24)
+    ap.add_argument("--batch", type=int, default=0, help="rows of a *_batched op (the wide-batch sparse launch stamps its chunk workgroups)")
     a = ap.parse_args()
     K, N = map(int, a.shape.split("x"))
     dev = torch.device("cuda:0")
@@ -37,9 +38,9 @@ def main():
     lib.sqllm_debug_set_timeline.restype = None
     layers = [synth.make_layer(K, N, a.bits, sparse_frac=a.sparse, topX=a.topx, heavy_rows=10 if a.sparse else 0, device=dev, seed=i)
               for i in range(a.copies * a.group)]
-    x = torch.randn(K, device=dev)
-    ys = [torch.zeros(N, device=dev) for _ in layers]
-    seq = decode.OpSequence(layers, [x] * len(layers), ys, fuse_shared_input=a.group > 1)
+    x = torch.randn((a.batch, K) if a.batch else K, device=dev)
+    ys = [torch.zeros((a.batch, N) if a.batch else N, device=dev) for _ in layers]
+    seq = decode.OpSequence(layers, [x] * len(layers), ys, batched=a.batch > 0, fuse_shared_input=a.group > 1)
     plan = _lib.plan_query(a.bits, K, N, nnz=0 if not a.sparse else layers[0]["vals"].numel(), topX=a.topx)
     wgs = max(4096, a.group * ((plan["grid_x"] + 7) // 8 * 8))  # (the streaming kernel plans its own grid: be generous)
     buf = torch.zeros((len(seq.groups), wgs, 8), dtype=torch.int64, device=dev)
@@ -49,7 +50,7 @@ def main():
     # one launch per group with its own probe buffer
     for gi, grp in enumerate(seq.groups):
         lib.sqllm_debug_set_timeline(ctypes.c_void_p(buf[gi].data_ptr()))
-        sub = decode.OpSequence([layers[i] for i in grp], [x] * len(grp), [ys[i] for i in grp], fuse_shared_input=a.group > 1)
+        sub = decode.OpSequence([layers[i] for i in grp], [x] * len(grp), [ys[i] for i in grp], batched=a.batch > 0, fuse_shared_input=a.group > 1)
         sub.launch()
         torch.cuda.synchronize()
     lib.sqllm_debug_set_timeline(None)
@@ -60,23 +61,25 @@ def main():
         g = t[gi]
         c = raw[gi][raw[gi][:, 0] < 0].astype(np.float64) / 100.0  # CSR chunk workgroups stamp their entry negated
         g = g[g[:, 0] > 0]  # dense workgroups only
-        t0 = g[:, 0].min()
+        t0 = g[:, 0].min() if len(g) else np.inf
         if len(c):
             c[:, 0] = -c[:, 0]
             t0 = min(t0, c[:, 0].min())
             d = np.diff(c[:, :6], axis=1)
             crows.append([np.percentile(c[:, 0] - t0, 50)] + [np.percentile(d[:, i], 50) for i in range(5)] +
                          [np.percentile(c[:, 5] - c[:, 0], 50), (c[:, 5] - t0).max(), len(c)])
-        rows.append([np.percentile(g[:, 0] - t0, 50), (g[:, 0] - t0).max(), np.percentile(g[:, 1] - g[:, 0], 50),
+        if len(g):
+          rows.append([np.percentile(g[:, 0] - t0, 50), (g[:, 0] - t0).max(), np.percentile(g[:, 1] - g[:, 0], 50),
                      np.percentile(g[:, 2] - g[:, 1], 50), np.percentile(g[:, 3] - g[:, 2], 50),
                      np.percentile(g[:, 3] - t0, 50), (g[:, 3] - t0).max(), (g[:, 4:8].max(axis=1) - g[:, 2]).mean(), len(g)])
-    r = np.array(rows).mean(axis=0)
-    print(f"shape {a.shape} x{a.group} w{a.bits} sparse {a.sparse}: kernel (events) {us[2:].mean():.2f} us, dense workgroups {int(r[8])}")
-    print(f"  workgroup entry after the first one     : median {r[0]:.2f} us, last {r[1]:.2f} us")
-    print(f"  entry -> codebook barrier passed        : median {r[2]:.2f} us")
-    print(f"  barrier -> wave 0 done decoding         : median {r[3]:.2f} us   (slowest of waves 0-3 finishes {r[7]:+.2f} us later)")
-    print(f"  wave 0 decode end -> atomics issued     : median {r[4]:.2f} us")
-    print(f"  first entry -> atomics issued           : median {r[5]:.2f} us, last workgroup {r[6]:.2f} us")
+    print(f"shape {a.shape} x{a.group} w{a.bits} sparse {a.sparse} rows {max(a.batch, 1)}: launches per op (events) {us[2:].mean():.2f} us")
+    if rows:
+        r = np.array(rows).mean(axis=0)
+        print(f"  dense workgroups {int(r[8])}: entry after the first one: median {r[0]:.2f} us, last {r[1]:.2f} us")
+        print(f"  entry -> codebook barrier passed        : median {r[2]:.2f} us")
+        print(f"  barrier -> wave 0 done decoding         : median {r[3]:.2f} us   (slowest of waves 0-3 finishes {r[7]:+.2f} us later)")
+        print(f"  wave 0 decode end -> atomics issued     : median {r[4]:.2f} us")
+        print(f"  first entry -> atomics issued           : median {r[5]:.2f} us, last workgroup {r[6]:.2f} us")
     if crows:
         c = np.array(crows).mean(axis=0)
         print(f"  CSR chunk workgroups ({int(c[8])}): entry {c[0]:.2f} us after the first workgroup; entry -> round 1 landed + counts {c[1]:.2f}, "
