@@ -259,3 +259,44 @@ def test_against_reference_kernels_live(gpu):
             assert H.rel_err(theirs.cpu().numpy(), want) <= TOL_FP64  # pins the oracle to the reference
             assert H.rel_err(ours.cpu().numpy(), want) <= TOL_FP64
             assert H.rel_err(ours.cpu().numpy(), theirs.cpu().numpy()) <= TOL_FP64
+
+
+def _csr_case(bits, K, N, row_lengths, seed):
+    """A dense term plus a CSR with exactly the given number of non-zeros in each row (columns sorted per row)."""
+    case = H.make_case(bits, K, N, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    rows = np.zeros(N + 1, np.int32)
+    rows[1:] = np.cumsum(row_lengths)
+    cols = np.concatenate([np.sort(rng.choice(K, size=int(n), replace=False)) for n in row_lengths] or [np.zeros(0)]).astype(np.int32)
+    vals = rng.normal(0, 0.1, cols.size).astype(np.float32)
+    case.update(rows=rows, cols=cols, vals=vals)
+    return case
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+def test_csr_row_segment_structures(qc, gpu, bits):
+    """The CSR role keeps two consecutive non-zeros per lane and scans the lanes' open row segments:
+    every way a row can meet a lane, a 16-lane DPP row, a wave and a chunk boundary -- rows of one non-zero (a row
+    end inside every lane), rows of two that start on odd positions, one row longer than several chunks, runs of
+    empty rows, and every total around the 64 / 128 / 1024 marks (the last lane half filled)."""
+    K, N = 2048, 192
+    patterns = {
+        "one each": np.ones(N, int),
+        "two each, shifted by one": np.r_[1, np.full(N - 1, 2)],
+        "three each": np.full(N, 3),
+        "one row holds 2500": np.r_[np.zeros(7, int), 2500 if K >= 2500 else K, np.zeros(N - 8, int)],
+        "heavy row between singles": np.r_[np.ones(50, int), 1500, np.ones(N - 51, int)],
+        "empty runs": np.where(np.arange(N) % 5 == 0, 37, 0),
+        "ramp": np.arange(N) % 40,
+    }
+    for total in (1, 2, 63, 64, 65, 127, 128, 129, 255, 257, 1023, 1024, 1025, 2047, 2049):
+        lens = np.zeros(N, int)
+        lens[: total // 11] = 11
+        lens[total // 11] = total % 11
+        patterns[f"{total} non-zeros in rows of 11"] = lens
+    patterns["one row holds 2500"][7] = min(2500, K)
+    for name, lens in patterns.items():
+        case = _csr_case(bits, K, N, lens, seed=len(name))
+        for batch in (0, 3, 8, 16, 40):  # fused kernel (1 / 4 / 8-row tiles), then the wide-batch sparse launch (lane groups / scalar walk)
+            x, mul, got = run_op(qc, gpu, case, "spmv", batch)
+            assert H.rel_err(got, H.oracle_ref(case, x, mul, "spmv")) <= TOL_FP64, (name, batch)
