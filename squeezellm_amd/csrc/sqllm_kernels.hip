@@ -519,10 +519,10 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
   }
   if (d >= 0 && d < gm.dense_blocks) {
     dense_role<BITS, BT, WAVES, ABL, XT, HALF>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, b0, nb,
-                                         d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds, sg, LIN ? &ga.seg[s] : nullptr);
+                                         d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds, sg, LIN ? &sg : nullptr);
   } else if (sp >= 0 && sp < gm.csr_blocks) {
     csr_role<T, BT, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds,
-                        LIN ? &ga.seg[s] : nullptr, gm.sparse_last >> 1, nullptr, 0,
+                        LIN ? &sg : nullptr, gm.sparse_last >> 1, nullptr, 0,
 #ifdef SQLLM_ABLATION_BUILD
                         (!LIN && sg.bias) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(sg.bias)) +
                                                 8ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y) : nullptr
