@@ -24,16 +24,55 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def fold_topx_into_csr(lay):
+    """(rows, cols, vals) of a layer's CSR with its top-X dense rows folded back in as ordinary CSR rows (an entry
+    present in both is summed), on the layer's device; cached in the layer dict under "csr_with_topx".
+
+    The reference keeps the few densest outlier rows as dense `full_rows` because its SpMV walks one row per
+    thread (quant_cuda_kernel.cu:1049-1058); the CSR role here is balanced by non-zeros, so a heavy row costs
+    nothing extra, and the FUSED LINEAR -- which has to fold the top-X rows into its dense tiles, its most
+    expensive term -- is faster with them in the CSR.  The operator path keeps the reference's
+    operands as they are."""
+    hit = lay.get("csr_with_topx")
+    if hit is not None:
+        return hit
+    full_rows, full_idx = lay["full_rows"], lay["full_row_indices"]
+    dev = full_rows.device
+    N, K = lay["N"], full_rows.shape[0]
+    if lay.get("vals") is not None and lay["vals"].numel():
+        rows, cols, vals = lay["rows"], lay["cols"], lay["vals"]
+        counts = (rows[1:] - rows[:-1]).to(torch.int64)
+        rid = torch.repeat_interleave(torch.arange(N, device=dev), counts)
+        cols = cols.to(torch.int64)
+    else:
+        rid = torch.zeros(0, dtype=torch.int64, device=dev)
+        cols = torch.zeros(0, dtype=torch.int64, device=dev)
+        vals = torch.zeros(0, dtype=full_rows.dtype, device=dev)
+    nz = (full_rows != 0).nonzero()  # (k, slot)
+    key = torch.cat([rid * K + cols, full_idx.to(torch.int64)[nz[:, 1]] * K + nz[:, 0]])
+    v = torch.cat([vals, full_rows[nz[:, 0], nz[:, 1]]])
+    order = torch.argsort(key, stable=True)
+    uniq, inv = torch.unique_consecutive(key[order], return_inverse=True)  # duplicates (CSR and top-X, or repeated indices): summed
+    v = torch.zeros(uniq.numel(), dtype=v.dtype, device=dev).index_add_(0, inv, v[order])
+    new_rows = torch.zeros(N + 1, dtype=torch.int32, device=dev)
+    new_rows[1:] = torch.bincount(uniq // K, minlength=N).cumsum(0).to(torch.int32)
+    out = (new_rows, (uniq % K).to(torch.int32).contiguous(), v.contiguous())
+    lay["csr_with_topx"] = out
+    return out
+
+
 class OpSequence:
     """A fixed list of ops `ys[i] += layer_i(xs[i])` with all pointers resolved up front."""
 
     def __init__(self, layers, xs, ys, batched: bool = False, fuse_shared_input: bool = False,
-                 linear: bool = False):
+                 linear: bool = False, fold_topx: bool = True):
         """fuse_shared_input: consecutive ops that read the SAME x tensor (and agree in K, bits,
         batch) are enqueued as one kernel (sqllm_launch_group), up to 4 per launch -- q/k/v and
         gate/up of a decoder layer.
         linear: `ys[i] = fp16(layer_i(xs[i]) + bias_i)` with fp16 xs / ys (ys overwritten) instead
-        of the operator semantics `ys[i] += layer_i(xs[i])` on fp32."""
+        of the operator semantics `ys[i] += layer_i(xs[i])` on fp32.
+        fold_topx (fused linears only): hand the kernel a CSR that contains the layer's top-X rows
+        (`fold_topx_into_csr`, built once per layer) instead of the separate dense rows."""
         if not (len(layers) == len(xs) == len(ys)):
             raise ValueError("layers, xs, ys must have equal length")
         self.n = len(layers)
@@ -59,12 +98,17 @@ class OpSequence:
             o = self.ops[i]
             o.bits, o.batch, o.K, o.N = lay["bits"], batch, K, N
             o.vec, o.qweight, o.mul, o.lookup_table = x.data_ptr(), lay["qweight"].data_ptr(), y.data_ptr(), lay["lookup_table"].data_ptr()
-            if lay.get("vals") is not None:
-                o.rows, o.cols, o.vals = _ptr(lay["rows"]), _ptr(lay["cols"]), _ptr(lay["vals"])
-                o.nnz = lay["vals"].numel()
-            if lay.get("full_rows") is not None:
-                o.full_rows, o.full_row_indices = _ptr(lay["full_rows"]), _ptr(lay["full_row_indices"])
-                o.topX = lay["full_rows"].shape[1]
+            if linear and fold_topx and lay.get("full_rows") is not None and lay["full_rows"].shape[1] > 0:
+                rows, cols, vals = fold_topx_into_csr(lay)  # (kept alive by the layer dict in _keep)
+                if vals.numel():
+                    o.rows, o.cols, o.vals, o.nnz = rows.data_ptr(), cols.data_ptr(), vals.data_ptr(), vals.numel()
+            else:
+                if lay.get("vals") is not None:
+                    o.rows, o.cols, o.vals = _ptr(lay["rows"]), _ptr(lay["cols"]), _ptr(lay["vals"])
+                    o.nnz = lay["vals"].numel()
+                if lay.get("full_rows") is not None:
+                    o.full_rows, o.full_row_indices = _ptr(lay["full_rows"]), _ptr(lay["full_row_indices"])
+                    o.topX = lay["full_rows"].shape[1]
             if linear:
                 bias = lay.get("bias")
                 if bias is not None and (bias.dtype != torch.float32 or not bias.is_cuda or bias.numel() != N):

@@ -165,6 +165,27 @@ class QuantLinearLUTFused(QuantLinearLUT):
                              "rows[N] == vals.numel()); the fused kernel counts contributions from `rows`")
         self.__dict__["_csr_ok"] = key
 
+    fold_topx = True  # fold the top-X dense rows into the CSR the fused kernel is given (set False to pass them separately)
+
+    def _csr_with_topx(self):
+        """(rows, cols, vals) with the top-X rows folded in, built once per buffer set (decode.fold_topx_into_csr);
+        not built while the stream is capturing -- that call then passes the top-X rows separately."""
+        from . import decode
+
+        has_csr = self.numvals > 0
+        key = (self.full_rows.data_ptr(), self.full_row_indices.data_ptr(), self.vals.data_ptr() if has_csr else 0, self.numvals)
+        hit = self.__dict__.get("_folded")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        lay = dict(N=self.outfeatures, full_rows=self.full_rows, full_row_indices=self.full_row_indices)
+        if has_csr:
+            lay.update(rows=self.rows, cols=self.cols, vals=self.vals)
+        out = decode.fold_topx_into_csr(lay)
+        self.__dict__["_folded"] = (key, out)
+        return out
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dtype != torch.float16 or not x.is_cuda:
             return super().forward(x)
@@ -183,9 +204,15 @@ class QuantLinearLUTFused(QuantLinearLUT):
         o.vec, o.qweight, o.mul, o.lookup_table = x2.data_ptr(), self.qweight.data_ptr(), out.data_ptr(), self.lookup_table.data_ptr()
         if self.include_sparse and self.numvals > 0:
             self._check_csr_once()
-            o.rows, o.cols, o.vals, o.nnz = self.rows.data_ptr(), self.cols.data_ptr(), self.vals.data_ptr(), self.vals.numel()
-        if self.include_sparse and self.topX > 0:  # independent of the CSR term (which may be empty)
-            o.full_rows, o.full_row_indices, o.topX = self.full_rows.data_ptr(), self.full_row_indices.data_ptr(), self.topX
+        folded = self._csr_with_topx() if self.include_sparse and self.topX > 0 and self.fold_topx else None
+        if folded is not None:  # one CSR term that contains the top-X rows (decode.fold_topx_into_csr)
+            if folded[2].numel():
+                o.rows, o.cols, o.vals, o.nnz = folded[0].data_ptr(), folded[1].data_ptr(), folded[2].data_ptr(), folded[2].numel()
+        else:
+            if self.include_sparse and self.numvals > 0:
+                o.rows, o.cols, o.vals, o.nnz = self.rows.data_ptr(), self.cols.data_ptr(), self.vals.data_ptr(), self.vals.numel()
+            if self.include_sparse and self.topX > 0:  # independent of the CSR term (which may be empty)
+                o.full_rows, o.full_row_indices, o.topX = self.full_rows.data_ptr(), self.full_row_indices.data_ptr(), self.topX
         lin.bias = None if self.bias is None else self.bias.data_ptr()
         lin.workspace = self._workspace(batch, x.device).data_ptr()
         with quant_cuda._on_device_of(x) as stream:

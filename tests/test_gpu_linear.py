@@ -99,7 +99,8 @@ def test_fuse_quant_lut_switches_children(gpu):
 
 @pytest.mark.parametrize("bits", [3, 4])
 @pytest.mark.parametrize("batched", [False, True])
-def test_linear_sequence_groups_and_graph(gpu, bits, batched):
+@pytest.mark.parametrize("fold", [True, False])
+def test_linear_sequence_groups_and_graph(gpu, bits, batched, fold):
     """A decoder layer's seven linears as fused-linear groups (q/k/v and gate/up share a launch),
     eager and replayed from a HIP graph."""
     import torch
@@ -116,8 +117,9 @@ def test_linear_sequence_groups_and_graph(gpu, bits, batched):
     xo = torch.randn((rows, hidden), device=gpu).half()
     xs = [xh, xh, xh, xo, xh, xh, xi]
     ys = [torch.full((rows, N), 7.0, device=gpu, dtype=torch.float16) for _, N in shapes]  # must be overwritten
-    seq = decode.OpSequence(lays, xs, ys, batched=batched, fuse_shared_input=True, linear=True)
+    seq = decode.OpSequence(lays, xs, ys, batched=batched, fuse_shared_input=True, linear=True, fold_topx=fold)
     assert [len(g) for g in seq.groups] == [3, 1, 2, 1]
+    assert all((seq.ops[i].topX == 0) == fold for i in range(7))  # top-X rows inside the CSR, or passed separately
     exact = [_exact(_npl(l), x.cpu().numpy(), "hybrid") for l, x in zip(lays, xs)]
     seq.launch()
     torch.cuda.synchronize()
@@ -297,3 +299,31 @@ def test_fused_linear_propagates_nan_and_inf_like_the_operator_path(gpu, bits, k
     assert (~torch.isfinite(want[rows - 1])).all(), "a poisoned row is non-finite in every column"
     ws = next(iter(fused._ws.values()))
     assert int(ws.count_nonzero()) == 0, "workspace must be left zero-filled"
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("rows", [1, 3])
+def test_fused_module_with_and_without_folded_topx(gpu, bits, rows):
+    """QuantLinearLUTFused hands the kernel one CSR that contains the top-X rows (default) or both terms separately:
+    the same fp16 result within an ulp of the oracle either way, including a layer whose outliers are ALL in the
+    top-X rows (empty CSR) and repeated top-X indices."""
+    import torch
+
+    from squeezellm_amd import quant, synth
+
+    K, N = 1024, 456
+    for sparse, dup in ((0.01, False), (0.0, False), (0.01, True)):
+        lay = synth.make_layer(K, N, bits, sparse_frac=sparse, topX=4, heavy_rows=2 if sparse else 0, bias=True, device=gpu, seed=bits + rows)
+        if dup:
+            lay["full_row_indices"][1] = lay["full_row_indices"][0]
+        x = torch.randn((rows, K), device=gpu).half()
+        exact = _exact(_npl(lay), x.cpu().numpy(), "hybrid")
+        outs = []
+        for fold in (True, False):
+            mod = quant.QuantLinearLUT.from_operands(lay)
+            mod.__class__ = quant.QuantLinearLUTFused
+            mod.fold_topx = fold
+            y = mod(x if rows > 1 else x.reshape(1, 1, K)).reshape(rows, N)
+            assert ("_folded" in mod.__dict__) == fold
+            _check_fp16(y.cpu().numpy(), exact)
+            outs.append(y)

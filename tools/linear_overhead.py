@@ -22,7 +22,7 @@ for bits in (3, 4):
             if key not in xin: xin[key] = torch.randn((l["K"],), device=dev).half()
             xs16.append(xin[key])
         ys16 = [torch.empty(l["N"], device=dev, dtype=torch.float16) for l in layers]
-        g3 = decode.OpSequence(layers, xs16, ys16, fuse_shared_input=True, linear=True).graph()
+        g3 = decode.OpSequence(layers, xs16, ys16, fuse_shared_input=True, linear=True, fold_topx=os.environ.get("FOLD_TOPX", "1") != "0").graph()
         x32 = {id(x): x.float() for x in xs16}
         ys32 = [torch.zeros(l["N"], device=dev) for l in layers]
         g4 = decode.OpSequence(layers, [x32[id(x)] for x in xs16], ys32, fuse_shared_input=True).graph()
