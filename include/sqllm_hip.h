@@ -259,6 +259,9 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     mfma_min_batch rows and more on the fp32 matrix cores, everything else on the
  *                     batch tiles of the batch-1 kernel.  Defaults (value 0 = measured default, which
  *                     depends on the bit width; get_option returns the stored 0): 4-bit 2..4 / 9, 3-bit 2..16 / 17.
+ *                     With the two cols_* options at their defaults the column-lane kernel is further reserved
+ *                     for the shapes it measured faster on: >= 20 MB of packed weights at up to 4 rows, or 3-bit
+ *                     with N >= 8192; setting either option takes the range at its word.
  *   "sparse_transpose" 1 (default): the CSR term of a wide-batch op reads a transposed copy of vec
  *                     (lane = batch row, coalesced); 0: it gathers from vec itself, as it does
  *                     anyway when no scratch can be had

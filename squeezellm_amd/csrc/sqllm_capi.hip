@@ -340,8 +340,20 @@ void make_plan_stream(const sqllm_op* ops, int n, int sparse_blocks, sqllm::Stre
   sa->n_dense = (int)((total + upw - 1) / upw);
 }
 
+// Does the column-lane kernel pay for this op?  Measured by shape (profiles/r03_tile_vs_cols_by_shape.txt, hybrid
+// ops, 2-16 rows): it wins by 5-19 % where the weights are large (>= 20 MB packed: a workgroup's table build and
+// scalar-load prologue amortise) or, for 3-bit, where there are many column tiles (N >= 8192); on the small
+// square ops (4096^2, 5120^2) the batch tiles win by 10-20 %.  Applied only while the routing options are at
+// their defaults: an explicit cols_min_batch / cols_max_batch is taken at its word.
+bool cols_pays(const sqllm_op* op) {
+  if (knobs().cols_min_batch.load(std::memory_order_relaxed) > 0 || knobs().cols_max_batch.load(std::memory_order_relaxed) > 0) return true;
+  const double mb = (double)op->K * op->N * op->bits / 8e6;
+  if (op->batch <= 4 && mb >= 20.0) return true;
+  return op->bits == 3 && op->N >= 8192;
+}
+
 bool takes_cols_path(const sqllm_op* op) {
-  return !takes_mfma_path(op) && op->batch >= 1 && op->batch >= cols_min_batch_of() && op->batch <= cols_max_batch_of(op);
+  return !takes_mfma_path(op) && op->batch >= 1 && op->batch >= cols_min_batch_of() && op->batch <= cols_max_batch_of(op) && cols_pays(op);
 }
 
 }  // namespace
