@@ -23,6 +23,7 @@ struct Knobs {
   std::atomic<int> ablate{0};
   std::atomic<int> lds_pad{0};  // measurement builds: unused dynamic LDS per workgroup, bytes
   std::atomic<int> sparse_last{0};
+  std::atomic<int> cols_groups{1};  // 0: a group of ops never takes the column-lane kernel (as before round 3)
   std::atomic<int> ablate_csr{0};
   // Routing of the *_batched operators by batch size (0 = the measured defaults, which depend on the bit width:
   // 13B gate/up shape, profiles/r02_batch_paths_*.txt):
@@ -215,7 +216,7 @@ bool takes_mfma_path(const sqllm_op* op) { return op->batch >= 1 && op->batch >=
 // (blockIdx.y); the dense work of a pass is cut into equal ranges of the flattened
 // (column tile, unit) space like make_plan_mfma's, three workgroups per CU (the phases of a
 // workgroup -- table build, decode, combine -- hide behind its neighbours').
-void make_plan_cols(const sqllm_op* op, sqllm::KernelGeom* gm) {
+void make_plan_cols(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1) {
   make_plan(op, gm, 1);
   const int bt = sqllm::batch_tile(gm->batch);
   const int grid_y = (gm->batch + bt - 1) / bt;
@@ -224,6 +225,7 @@ void make_plan_cols(const sqllm_op* op, sqllm::KernelGeom* gm) {
   if (upw <= 0) {
     int target = knobs().target_wgs.load(std::memory_order_relaxed);
     if (target <= 0) target = 3 * cu_count();
+    target = (target + ops_in_launch - 1) / ops_in_launch;  // the ops of a group share the launch's workgroups
     long long ranges = (target + grid_y - 1) / grid_y;
     if (ranges < 1) ranges = 1;
     upw = (total_units + ranges - 1) / ranges;
@@ -352,6 +354,15 @@ bool cols_pays(const sqllm_op* op) {
   return op->bits == 3 && op->N >= 8192;
 }
 
+// a group of ops over one vec (q/k/v, gate/up) is judged as the one op it is to the kernel: the sum of its columns
+bool group_takes_cols_path(const sqllm_op* ops, int n) {
+  sqllm_op sum = ops[0];
+  long long N = 0;
+  for (int i = 0; i < n; ++i) N += ops[i].N;
+  sum.N = N > 0x7fffffff ? 0x7fffffff : (int)N;
+  return !takes_mfma_path(&ops[0]) && sum.batch >= 1 && sum.batch >= cols_min_batch_of() && sum.batch <= cols_max_batch_of(&sum) && cols_pays(&sum);
+}
+
 bool takes_cols_path(const sqllm_op* op) {
   return !takes_mfma_path(op) && op->batch >= 1 && op->batch >= cols_min_batch_of() && op->batch <= cols_max_batch_of(op) && cols_pays(op);
 }
@@ -396,6 +407,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "target_wgs")) { knobs().target_wgs.store(value); return SQLLM_OK; }
   if (!strcmp(name, "groups_per_wave")) { knobs().groups_per_wave.store(value); return SQLLM_OK; }
   if (!strcmp(name, "sparse_last")) { knobs().sparse_last.store(value ? 1 : 0); return SQLLM_OK; }
+  if (!strcmp(name, "cols_groups")) { knobs().cols_groups.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { knobs().cu_count.store(value); return SQLLM_OK; }  // for GPU-less planning tests
   if (!strcmp(name, "mfma_min_batch")) { knobs().mfma_min_batch.store(value); return SQLLM_OK; }
   if (!strcmp(name, "cols_min_batch")) { knobs().cols_min_batch.store(value); return SQLLM_OK; }
@@ -421,6 +433,7 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "groups_per_wave")) { *value = knobs().groups_per_wave.load(); return SQLLM_OK; }
   if (!strcmp(name, "cu_count")) { *value = knobs().cu_count.load(); return SQLLM_OK; }
   if (!strcmp(name, "sparse_last")) { *value = knobs().sparse_last.load(); return SQLLM_OK; }
+  if (!strcmp(name, "cols_groups")) { *value = knobs().cols_groups.load(); return SQLLM_OK; }
   if (!strcmp(name, "mfma_min_batch")) { *value = knobs().mfma_min_batch.load(); return SQLLM_OK; }
   if (!strcmp(name, "cols_min_batch")) { *value = knobs().cols_min_batch.load(); return SQLLM_OK; }
   if (!strcmp(name, "cols_max_batch")) { *value = knobs().cols_max_batch.load(); return SQLLM_OK; }
@@ -475,6 +488,39 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
   // (the column-lane kernel only for an op that is alone in its launch: q/k/v or gate/up sharing one
   // launch of the batch tiles beat three / two launches of it -- 13B s45 decoder layer at 2 rows:
   // 88 vs 101 us)
+  if (!lin && n > 1 && knobs().cols_groups.load(std::memory_order_relaxed) && group_takes_cols_path(ops, n)) {
+    // a group on the column-lane kernel: ONE launch, the workgroups divided between the ops
+    sqllm::LaunchArgs a;
+    a.ev_start = e0;
+    a.ev_stop = e1;
+    a.x = ops[0].vec;
+    a.ga.n_seg = n;
+    memset(a.ga.seg, 0, sizeof(a.ga.seg));
+    int block = 0;
+    for (int i = 0; i < n; ++i) {
+      const sqllm_op* op = &ops[i];
+      int rc = validate(op);
+      if (rc == SQLLM_OK) rc = validate_csr_values(op, stream);
+      if (rc != SQLLM_OK) return rc;
+      if (op->vec != ops[0].vec || op->K != ops[0].K || op->bits != ops[0].bits || op->batch != ops[0].batch)
+        return SQLLM_E_GROUP;
+      if ((uint64_t)op->batch * (uint64_t)op->K >= (1ull << 31)) return SQLLM_E_SHAPE;  // 32-bit row offsets into vec
+      sqllm::Segment& sg = a.ga.seg[i];
+      sg.q = reinterpret_cast<const uint32_t*>(op->qweight);
+      sg.y = op->mul;
+      sg.lut = op->lookup_table;
+      sg.rows = op->rows;
+      sg.cols = op->cols;
+      sg.vals = op->vals;
+      sg.full_rows = op->topX > 0 ? op->full_rows : nullptr;
+      sg.full_idx = op->topX > 0 ? op->full_row_indices : nullptr;
+      make_plan_cols(op, &sg.gm, n);
+      a.ga.block0[i] = block;
+      block += (sg.gm.dense_block0 + sg.gm.dense_blocks + 7) / 8 * 8;
+    }
+    for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
+    return static_cast<int>(sqllm::launch_batched_cols(ops[0].bits, a, static_cast<hipStream_t>(stream)));
+  }
   if (!lin && (takes_mfma_path(&ops[0]) || (n == 1 && takes_cols_path(&ops[0])))) {
     // batched operators: one launch per op (the members of a group only share their input) of the
     // matrix-core kernel (wide batches) or of the column-lane kernel (small ones)

@@ -1170,11 +1170,24 @@ __global__ void __launch_bounds__(WAVES * 64)
 sqllm_fused_cols(const float* x, const GroupArgs ga) {
   constexpr int T = WAVES * 64;
   __shared__ __attribute__((aligned(16))) float lds[cols_lds_floats(BITS, BT, WAVES)];
-  const Segment sg = ga.seg[0];  // the whole descriptor in one round of scalar loads (see sqllm_fused_matvec)
-  asm volatile("" ::SQLLM_SEG_OPERANDS(sg), "s"(x));
+  // up to kMaxSegments ops over the same vec (q/k/v, gate/up): workgroup ids [block0[s], block0[s+1]) belong to op s.
+  // Segment 0's descriptor and the block table in one round of scalar loads (see sqllm_fused_matvec), another
+  // segment's in one more.
+  Segment sg = ga.seg[0];
+  const int n_seg = ga.n_seg, blk1 = ga.block0[1], blk2 = ga.block0[2], blk3 = ga.block0[3];
+  asm volatile("" ::SQLLM_SEG_OPERANDS(sg), "s"(x), "s"(n_seg), "s"(blk1), "s"(blk2), "s"(blk3));
   __builtin_amdgcn_sched_barrier(0);
+  int bid = blockIdx.x;
+  int s = 0;
+  if (n_seg > 1 && bid >= blk1) s = 1;
+  if (n_seg > 2 && bid >= blk2) s = 2;
+  if (n_seg > 3 && bid >= blk3) s = 3;
+  if (s != 0) {
+    sg = ga.seg[s];
+    asm volatile("" ::SQLLM_SEG_OPERANDS(sg));
+    bid -= s == 1 ? blk1 : s == 2 ? blk2 : blk3;
+  }
   const KernelGeom& gm = sg.gm;
-  const int bid = blockIdx.x;
   const int b0 = blockIdx.y * BT;
   int nb = gm.batch - b0;
   if (nb > BT) nb = BT;
@@ -1321,7 +1334,7 @@ static hipError_t launch_mfma_bits(const LaunchArgs& a, hipStream_t stream) {
 template <int BITS, int BT>
 static hipError_t launch_cols_inst(const LaunchArgs& a, hipStream_t stream) {
   const KernelGeom& gm = a.ga.seg[0].gm;
-  dim3 grid(gm.dense_block0 + gm.dense_blocks, (gm.batch + BT - 1) / BT);
+  dim3 grid(a.ga.block0[a.ga.n_seg], (gm.batch + BT - 1) / BT);
   auto kern = sqllm_fused_cols<BITS, BT, kWaves>;
   const float* x = static_cast<const float*>(a.x);
   if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga);
@@ -1339,7 +1352,7 @@ static hipError_t launch_cols_bits(const LaunchArgs& a, hipStream_t stream) {
   }
 }
 
-// one op (a.ga.seg[0]), operator ABI, small batches: lane = column, vec from SGPRs
+// 1..kMaxSegments ops over one vec (a.ga), operator ABI, small batches: lane = column, vec from SGPRs
 hipError_t launch_batched_cols(int bits, const LaunchArgs& a, hipStream_t stream) {
   return bits == 4 ? launch_cols_bits<4>(a, stream) : launch_cols_bits<3>(a, stream);
 }

@@ -260,7 +260,7 @@ def test_every_documented_option_round_trips():
     assert {"target_wgs", "groups_per_wave", "sparse_last", "cu_count", "mfma_min_batch", "cols_min_batch", "cols_max_batch",
             "sparse_transpose", "scratch_in_capture", "validate_csr"} <= set(names)
     defaults = {"mfma_min_batch": 0, "cols_min_batch": 0, "cols_max_batch": 0, "sparse_transpose": 1, "scratch_in_capture": 1,
-                "validate_csr": 0, "sparse_last": 0, "target_wgs": 0, "groups_per_wave": 0}
+                "validate_csr": 0, "sparse_last": 0, "target_wgs": 0, "groups_per_wave": 0, "cols_groups": 1}
     for n in names:
         before = _lib.get_option(n)
         if n in defaults:

@@ -86,7 +86,47 @@ def test_column_lane_kernel_vs_oracle(qc, gpu, bits, kind, shape):
             torch.cuda.synchronize()
             assert H.rel_err(y.cpu().numpy(), H.oracle_ref(case, x, mul, kind)) <= TOL_FP64, (B, K, N)
     finally:
-        _routing(0, 2, 0)
+        _routing(0, 0, 0)
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("kind", ["dense", "hybrid"])
+def test_column_lane_kernel_runs_groups(gpu, bits, kind):
+    """q/k/v-style groups (one vec, ops of DIFFERENT, ragged widths) as ONE launch of the column-lane kernel -- the
+    workgroups divided between the ops through the block table -- against the oracle, and with the option that
+    keeps groups on the batch tiles."""
+    import torch
+
+    from squeezellm_amd import _lib, decode
+
+    K, Ns = 1024, (776, 132, 260, 64)
+    cases = [H.make_case(bits, K, N, sparse=0.02 if kind == "hybrid" else 0, topX=3 if kind == "hybrid" else 0,
+                         heavy_rows=1 if kind == "hybrid" else 0, seed=N + bits) for N in Ns]
+    lays = []
+    for c in cases:
+        t = H.to_torch(c, gpu)
+        lays.append(dict(bits=bits, K=K, N=c["N"], qweight=t["qweight"], lookup_table=t["lookup_table"], rows=t.get("rows"),
+                         cols=t.get("cols"), vals=t.get("vals"), full_rows=t.get("full_rows"), full_row_indices=t.get("full_row_indices")))
+    try:
+        _routing(1 << 30, 1, 1 << 30)
+        for B in (1, 2, 3, 4, 8, 9, 16):
+            rng = np.random.default_rng(B)
+            x = rng.normal(size=(B, K)).astype(np.float32)
+            xt = torch.from_numpy(x).to(gpu)
+            refs = [H.oracle_ref(c, x, np.zeros((B, c["N"]), np.float32), kind) for c in cases]
+            for groups in (1, 0):
+                _lib.set_option("cols_groups", groups)
+                for n in (2, 3, 4):
+                    ys = [torch.zeros((B, c["N"]), device=gpu) for c in cases[:n]]
+                    seq = decode.OpSequence(lays[:n], [xt] * n, ys, batched=True, fuse_shared_input=True)
+                    assert [len(g) for g in seq.groups] == [n]
+                    seq.launch()
+                    torch.cuda.synchronize()
+                    for y, r in zip(ys, refs):
+                        assert H.rel_err(y.cpu().numpy(), r) <= TOL_FP64, (B, groups, n)
+    finally:
+        _lib.set_option("cols_groups", 1)
+        _routing(0, 0, 0)
 
 
 @pytest.mark.parametrize("bits", [3, 4])
@@ -107,7 +147,7 @@ def test_three_batched_paths_agree(qc, gpu, bits):
                 torch.cuda.synchronize()
                 outs.append(y.cpu().numpy())
         finally:
-            _routing(0, 2, 0)
+            _routing(0, 0, 0)
         assert H.rel_err(outs[1], outs[0]) <= 1e-5 and H.rel_err(outs[2], outs[0]) <= 1e-5
 
 
