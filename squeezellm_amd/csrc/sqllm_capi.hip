@@ -342,16 +342,18 @@ void make_plan_stream(const sqllm_op* ops, int n, int sparse_blocks, sqllm::Stre
   sa->n_dense = (int)((total + upw - 1) / upw);
 }
 
-// Does the column-lane kernel pay for this op?  Measured by shape (profiles/r03_tile_vs_cols_by_shape.txt, hybrid
-// ops, 2-16 rows): it wins by 5-19 % where the weights are large (>= 20 MB packed: a workgroup's table build and
-// scalar-load prologue amortise) or, for 3-bit, where there are many column tiles (N >= 8192); on the small
-// square ops (4096^2, 5120^2) the batch tiles win by 10-20 %.  Applied only while the routing options are at
-// their defaults: an explicit cols_min_batch / cols_max_batch is taken at its word.
-bool cols_pays(const sqllm_op* op) {
+// Does the column-lane kernel pay?  Measured by shape and group size (profiles/r03_tile_vs_cols_by_shape.txt, hybrid
+// ops, 2-16 rows).  4-bit: since the 2- and 4-row batch tiles fit three workgroups per CU it wins only on GROUPS OF
+// THREE ops (q/k/v: -6...-14 %); single ops and two-op groups (gate/up) are 5-19 % faster on the tiles.  3-bit: it
+// wins by 5-19 % where the weights are large (>= 20 MB packed, up to 4 rows) or there are many column tiles
+// (N >= 8192); on the small square ops the batch tiles win by 10-20 %.  Applied only while the routing options are
+// at their defaults: an explicit cols_min_batch / cols_max_batch is taken at its word.
+bool cols_pays(const sqllm_op* op, int n_ops) {
   if (knobs().cols_min_batch.load(std::memory_order_relaxed) > 0 || knobs().cols_max_batch.load(std::memory_order_relaxed) > 0) return true;
+  if (op->bits == 4) return n_ops >= 3;
   const double mb = (double)op->K * op->N * op->bits / 8e6;
   if (op->batch <= 4 && mb >= 20.0) return true;
-  return op->bits == 3 && op->N >= 8192;
+  return op->N >= 8192;
 }
 
 // a group of ops over one vec (q/k/v, gate/up) is judged as the one op it is to the kernel: the sum of its columns
@@ -360,11 +362,11 @@ bool group_takes_cols_path(const sqllm_op* ops, int n) {
   long long N = 0;
   for (int i = 0; i < n; ++i) N += ops[i].N;
   sum.N = N > 0x7fffffff ? 0x7fffffff : (int)N;
-  return !takes_mfma_path(&ops[0]) && sum.batch >= 1 && sum.batch >= cols_min_batch_of() && sum.batch <= cols_max_batch_of(&sum) && cols_pays(&sum);
+  return !takes_mfma_path(&ops[0]) && sum.batch >= 1 && sum.batch >= cols_min_batch_of() && sum.batch <= cols_max_batch_of(&sum) && cols_pays(&sum, n);
 }
 
 bool takes_cols_path(const sqllm_op* op) {
-  return !takes_mfma_path(op) && op->batch >= 1 && op->batch >= cols_min_batch_of() && op->batch <= cols_max_batch_of(op) && cols_pays(op);
+  return !takes_mfma_path(op) && op->batch >= 1 && op->batch >= cols_min_batch_of() && op->batch <= cols_max_batch_of(op) && cols_pays(op, 1);
 }
 
 }  // namespace

@@ -196,7 +196,7 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   constexpr int ESTRIDE = (BITS == 4) ? 256 : 128;                 // bytes between consecutive entries
   constexpr int SUBB = (BITS == 4) ? (L * ESTRIDE) / 2 : L * ESTRIDE;  // LDS bytes per column sub-table
   // steps per chunk (4-bit: even, steps pair up for x; 3-bit: 12 VGPRs of weights per step)
-  constexpr int NBUF = (BITS == 4) ? (BT <= 4 ? 4 : 2) : ((BT == 1 && !HALF) ? 2 : 1);
+  constexpr int NBUF = (BITS == 4) ? (BT <= 2 ? 4 : 2) : ((BT == 1 && !HALF) ? 2 : 1);
   constexpr int NXR = (BITS == 4) ? NBUF / 2 : 2 * NBUF;  // x registers per chunk and batch row
   constexpr int STEP = WAVES * 4;                // units a workgroup step covers
   const int tid = threadIdx.x;
@@ -471,7 +471,7 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
 // (16 live lookups instead of 32), which lets the batch-1 kernels fit 64 VGPRs, i.e. FOUR 8-wave
 // workgroups per CU; the wider batch tiles take what they need up to 128 (two per CU).
 template <int BITS, int BT, int WAVES, int ABL, bool LIN>
-__global__ void __launch_bounds__(WAVES * 64, (ABL & 64) ? 8 : ((BT == 1 && SQLLM_HALF_STAGES) ? 8 : 4))
+__global__ void __launch_bounds__(WAVES * 64, (ABL & 64) ? 8 : ((BT == 1 && SQLLM_HALF_STAGES) ? 8 : ((BT == 2 || (BT == 4 && BITS == 4)) ? 6 : 4)))
 sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
   constexpr bool HALF = SQLLM_HALF_STAGES && BT == 1;  // wider batch tiles: the per-row x broadcasts would be live twice
   constexpr int T = WAVES * 64;
