@@ -57,7 +57,9 @@ ABLATION_LIB_PATH = os.path.join(HERE, ABLATION_LIB_NAME)
 # measurement-only preprocessor switches (environment variable -> macro).  They select kernel variants that
 # are slower or deliberately WRONG (ablations); a build that sets any of them is an ablation build and can
 # only be written to libsqllm_hip_ablation.so, never to the product library.
-VARIANT_ENV = ("SQLLM_WAVES", "SQLLM_PAIR3", "SQLLM_HALF_STAGES", "SQLLM_PAIR3_NOCONFLICT", "SQLLM_MFMA_VAR", "SQLLM_MFMA_FAKE", "SQLLM_TOPX_ROWS", "SQLLM_CSR_CHUNK")
+# (SQLLM_WAVES=4, round 2's 4-wave workgroups, is gone from the list: the column-lane kernel, the top-X role and the CSR
+# role's lane runs are written for 8 waves and say so in static_asserts)
+VARIANT_ENV = ("SQLLM_PAIR3", "SQLLM_HALF_STAGES", "SQLLM_PAIR3_NOCONFLICT", "SQLLM_MFMA_VAR", "SQLLM_MFMA_FAKE", "SQLLM_TOPX_ROWS", "SQLLM_CSR_CHUNK")
 
 
 def _compile(out: str, extra, verbose: bool, sources=None) -> str:
