@@ -141,10 +141,12 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1,
       // measured on MI355X (tools/sweep.py, bench.py): an op under ~12 MB of packed weights runs
       // best with one 8-wave workgroup per CU when it shares its launch with others (q/k/v) and
       // with two when it is alone (o_proj); larger ones with ~3 per CU (gate/up) or 4 when alone
-      // (down_proj) -- the chip holds four per CU
+      // (down_proj) -- the chip holds four per CU.  In between (the 13B q/k/v at 4 bits, 13 MB each, sharing a
+      // launch): two per CU and op -- three made 2400 workgroups of the group, 6 % slower
+      // (profiles/r03_target_wgs_groups_batch1.txt)
       const double mb = (double)op->K * op->N * op->bits / 8.0 / 1e6;
       const bool alone = ops_in_launch <= 1;
-      target = (mb <= 12.0 ? (alone ? 2 : 1) : (alone ? 4 : 3)) * cu_count();
+      target = (mb <= 12.0 ? (alone ? 2 : 1) : (!alone && mb <= 16.0) ? 2 : (alone ? 4 : 3)) * cu_count();
       if (waves > sqllm::kWaves) target = target * sqllm::kWaves / waves;  // (16-wave workgroups: half as many, twice the rows each)
     }
     int slices = (target + gm->col_tiles / 2) / gm->col_tiles;
