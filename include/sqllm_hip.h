@@ -260,8 +260,9 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     batch tiles of the batch-1 kernel.  Defaults (value 0 = measured default, which
  *                     depends on the bit width; get_option returns the stored 0): 4-bit 2..4 / 9, 3-bit 2..16 / 17.
  *                     With the two cols_* options at their defaults the column-lane kernel is further reserved
- *                     for what it measured faster on: 4-bit, groups of three or more ops; 3-bit, >= 20 MB of
- *                     packed weights at up to 4 rows or N >= 8192; setting either option takes the range at its word.
+ *                     for what it measured faster on: 4-bit, groups of three or more ops and single ops of
+ *                     >= 20 MB packed weights; 3-bit, >= 16 MB at up to 4 rows or N >= 8192; setting either option
+ *                     takes the range at its word.
  *   "cols_groups"     1 (default): a GROUP of ops over one vec (sqllm_launch_group) may take the column-lane kernel
  *                     too, as one launch, judged by the sum of its columns; 0: groups stay on the batch tiles
  *   "sparse_transpose" 1 (default): the CSR term of a wide-batch op reads a transposed copy of vec

@@ -224,6 +224,7 @@ void make_plan_cols(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch
   const int grid_y = (gm->batch + bt - 1) / bt;
   const long long total_units = (long long)gm->col_tiles * gm->units_total;
   long long upw = (long long)knobs().groups_per_wave.load(std::memory_order_relaxed) * sqllm::kWaves;
+  bool aligned = false;
   if (upw <= 0) {
     int target = knobs().target_wgs.load(std::memory_order_relaxed);
     if (target <= 0) target = 3 * cu_count();
@@ -231,12 +232,26 @@ void make_plan_cols(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch
     long long ranges = (target + grid_y - 1) / grid_y;
     if (ranges < 1) ranges = 1;
     upw = (total_units + ranges - 1) / ranges;
+    // A range that crosses a column-tile boundary is worked off as two pieces, each with its own table build.
+    // Where a whole number of ranges per tile comes within 10 % of the wanted count, cut the tiles that way
+    // instead (K = 5120: 640 units per tile against ranges of 200 -- two of three ranges crossed; the 5120-wide
+    // ops were the one family the column-lane kernel lost on, profiles/r03_tile_vs_cols_by_shape.txt).
+    const long long upw8 = (upw + sqllm::kWaves - 1) / sqllm::kWaves * sqllm::kWaves;
+    const long long need = (gm->units_total + upw8 - 1) / upw8;  // ranges of that length a tile needs
+    for (long long per_tile = need; per_tile >= 1 && per_tile >= need - 1 && !aligned; --per_tile) {
+      long long even = (gm->units_total + per_tile - 1) / per_tile;
+      even = (even + sqllm::kWaves - 1) / sqllm::kWaves * sqllm::kWaves;
+      const long long n_even = (long long)gm->col_tiles * ((gm->units_total + even - 1) / even);
+      if (n_even <= ranges && 10 * n_even >= 9 * ranges) { upw = even; aligned = true; }
+    }
   }
   upw = (upw + sqllm::kWaves - 1) / sqllm::kWaves * sqllm::kWaves;
   if (upw > 0x3fffffff) upw = 0x3fffffff / sqllm::kWaves * sqllm::kWaves;
   gm->units_per_wg = (int)upw;
   gm->k_slices = (int)((gm->units_total + upw - 1) / upw);
-  gm->dense_blocks = (int)((total_units + upw - 1) / upw);
+  // (the kernel recognises the tile-aligned cut by dense_blocks == col_tiles * k_slices -- which, when it holds
+  // for a contiguous cut too, describes the same ranges)
+  gm->dense_blocks = aligned ? gm->col_tiles * gm->k_slices : (int)((total_units + upw - 1) / upw);
   gm->sparse_last = 0;
   gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
 }
@@ -345,16 +360,17 @@ void make_plan_stream(const sqllm_op* ops, int n, int sparse_blocks, sqllm::Stre
 }
 
 // Does the column-lane kernel pay?  Measured by shape and group size (profiles/r03_tile_vs_cols_by_shape.txt, hybrid
-// ops, 2-16 rows).  4-bit: since the 2- and 4-row batch tiles fit three workgroups per CU it wins only on GROUPS OF
-// THREE ops (q/k/v: -6...-14 %); single ops and two-op groups (gate/up) are 5-19 % faster on the tiles.  3-bit: it
-// wins by 5-19 % where the weights are large (>= 20 MB packed, up to 4 rows) or there are many column tiles
-// (N >= 8192); on the small square ops the batch tiles win by 10-20 %.  Applied only while the routing options are
-// at their defaults: an explicit cols_min_batch / cols_max_batch is taken at its word.
+// ops, 2-16 rows), after the 2- / 4-row batch tiles went to three workgroups per CU and the column-lane kernel
+// to tile-aligned ranges.  4-bit: groups of THREE ops (q/k/v: -6...-14 %) and single ops of >= 20 MB packed weights
+// (down_proj: -7...-8 %); small single ops and two-op groups (gate/up, whose tile count does not cut evenly) are
+// 5-19 % faster on the tiles.  3-bit: >= 16 MB packed at up to 4 rows, or many column tiles (N >= 8192); the small
+// square ops stay on the tiles.  Applied only while the routing options are at their defaults: an explicit
+// cols_min_batch / cols_max_batch is taken at its word.
 bool cols_pays(const sqllm_op* op, int n_ops) {
   if (knobs().cols_min_batch.load(std::memory_order_relaxed) > 0 || knobs().cols_max_batch.load(std::memory_order_relaxed) > 0) return true;
-  if (op->bits == 4) return n_ops >= 3;
-  const double mb = (double)op->K * op->N * op->bits / 8e6;
-  if (op->batch <= 4 && mb >= 20.0) return true;
+  const double mb = (double)op->K * op->N * op->bits / 8e6;  // (of a group: the sum of its ops)
+  if (op->bits == 4) return n_ops >= 3 || (n_ops == 1 && mb >= 20.0);
+  if (op->batch <= 4 && mb >= 16.0) return true;
   return op->N >= 8192;
 }
 

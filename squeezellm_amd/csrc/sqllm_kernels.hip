@@ -983,7 +983,7 @@ template <int BITS, int BT, int WAVES>
 __device__ __forceinline__ void dense_role_cols(const float* __restrict__ x, const uint32_t* __restrict__ q,
                                                 float* __restrict__ y, const float* __restrict__ lut, int K, int N,
                                                 int b0, int nb, int bid, int n_col_tiles, int units_total,
-                                                int units_per_wg, float* lds) {
+                                                int units_per_wg, int units_stride, float* lds) {
   using F = Fmt<BITS>;
   constexpr int L = F::kLut, R = F::kRows, KU = F::kK;
   constexpr int ST = cols_stage_k(BT);        // k's per stage
@@ -1019,17 +1019,23 @@ __device__ __forceinline__ void dense_role_cols(const float* __restrict__ x, con
   if constexpr (BITS == 4) { if (tid < 64) *reinterpret_cast<float*>(table + 16 * 256 + 4 * tid) = 0.f; }
   else { if (tid < 64) *reinterpret_cast<f32x2*>(table + 64 * 512 + 8 * tid) = f32x2{0.f, 0.f}; }
 
-  const unsigned total = (unsigned)n_col_tiles * (unsigned)units_total;
+  // The ranges live in a flattened (column tile, unit) space in which a tile is units_stride long: = units_total
+  // (contiguous ranges, some crossing a tile boundary: two pieces, two table builds) or, where the plan could cut
+  // every tile into a whole number of ranges, that number x units_per_wg (>= units_total: no range crosses, the
+  // last one of a tile is short).
+  const unsigned total = (unsigned)n_col_tiles * (unsigned)units_stride;
   unsigned gpos = (unsigned)bid * (unsigned)units_per_wg;
   unsigned gend = gpos + (unsigned)units_per_wg;
   if (gend > total) gend = total;
   bool first = true;
   while (gpos < gend) {
-    const int ct = __builtin_amdgcn_readfirstlane((int)(gpos / (unsigned)units_total));  // (the division runs on the VALU)
-    const int u0 = (int)(gpos - (unsigned)ct * (unsigned)units_total);
+    const int ct = __builtin_amdgcn_readfirstlane((int)(gpos / (unsigned)units_stride));  // (the division runs on the VALU)
+    const int u0 = (int)(gpos - (unsigned)ct * (unsigned)units_stride);
+    if (u0 >= units_total) { gpos = (unsigned)(ct + 1) * (unsigned)units_stride; continue; }  // (padding behind a tile's last range)
     int u1 = units_total;
     if ((unsigned)(u1 - u0) > gend - gpos) u1 = u0 + (int)(gend - gpos);
     gpos += (unsigned)(u1 - u0);
+    if (u1 == units_total) gpos = (unsigned)(ct + 1) * (unsigned)units_stride;  // skip the padding
     const int col0 = ct * kTileN;
     const int col = col0 + lane;
     const int colc = col < N ? col : N - 1;
@@ -1195,7 +1201,8 @@ sqllm_fused_cols(const float* x, const GroupArgs ga) {
   const int sp = bid < gm.dense_block0 ? bid : -1;
   if (d >= 0 && d < gm.dense_blocks) {
     dense_role_cols<BITS, BT, WAVES>(x, sg.q, sg.y, sg.lut, gm.K, gm.N, b0, nb, d, gm.col_tiles, gm.units_total,
-                                     gm.units_per_wg, lds);
+                                     gm.units_per_wg,
+                                     gm.dense_blocks == gm.col_tiles * gm.k_slices ? gm.k_slices * gm.units_per_wg : gm.units_total, lds);
   } else if (sp >= 0 && sp < gm.csr_blocks) {
     csr_role<T, BT, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds, nullptr, 0);
   } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
