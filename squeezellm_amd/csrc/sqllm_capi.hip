@@ -187,18 +187,28 @@ void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm) {
   const int step = sqllm::kWaves * 4;
   const long long total_units = (long long)gm->col_tiles * gm->units_total;
   long long upw = (long long)knobs().groups_per_wave.load(std::memory_order_relaxed) * step;
+  bool aligned = false;
   if (upw <= 0) {
     int target = knobs().target_wgs.load(std::memory_order_relaxed);
     if (target <= 0) target = (mb == 4 ? 1 : 2) * cu_count();
     long long ranges = (target + grid_y - 1) / grid_y;
     if (ranges < 1) ranges = 1;
     upw = (total_units + ranges - 1) / ranges;
+    // tile-aligned ranges where a whole number per tile comes within 10 % of the wanted count (see make_plan_cols)
+    const long long upws = (upw + step - 1) / step * step;
+    const long long need = (gm->units_total + upws - 1) / upws;
+    for (long long per_tile = need; per_tile >= 1 && per_tile >= need - 1 && !aligned; --per_tile) {
+      long long even = (gm->units_total + per_tile - 1) / per_tile;
+      even = (even + step - 1) / step * step;
+      const long long n_even = (long long)gm->col_tiles * ((gm->units_total + even - 1) / even);
+      if (n_even <= ranges && 10 * n_even >= 9 * ranges) { upw = even; aligned = true; }
+    }
   }
   upw = (upw + step - 1) / step * step;
   if (upw > 0x3fffffff) upw = 0x3fffffff / step * step;
   gm->units_per_wg = (int)upw;
   gm->k_slices = (int)((gm->units_total + upw - 1) / upw);  // pieces per column tile (reported by plan_query)
-  gm->dense_blocks = (int)((total_units + upw - 1) / upw);
+  gm->dense_blocks = aligned ? gm->col_tiles * gm->k_slices : (int)((total_units + upw - 1) / upw);
   gm->sparse_last = 0;
   gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
 }

@@ -581,7 +581,7 @@ template <int BITS, int MB, int WAVES>
 __device__ __forceinline__ void dense_role_mfma(const float* __restrict__ x, const u32x4* __restrict__ q,
                                                 float* __restrict__ y, const float* __restrict__ lut, int K, int N,
                                                 int batch, int m0, int bid, int n_col_tiles, int units_total,
-                                                int units_per_wg, float* lds) {
+                                                int units_per_wg, int units_stride, float* lds) {
   using F = Fmt<BITS>;
   constexpr int L = F::kLut, R = F::kRows, KU = F::kK;
   constexpr int NPH = KU / 8;          // phases of 8 k's per unit (4-bit: 1, 3-bit: 4)
@@ -635,16 +635,20 @@ __device__ __forceinline__ void dense_role_mfma(const float* __restrict__ x, con
   // (column tile, unit) space -- every workgroup the same number of units whatever N and K are, all
   // of them resident at once (one round, no tail).  A range that crosses a tile boundary is worked
   // off as two pieces (codebooks restaged, sums flushed in between). ----
-  const unsigned total = (unsigned)n_col_tiles * (unsigned)units_total;
+  // (a tile is units_stride long in the flattened space: units_total, or -- tile-aligned ranges, see dense_role_cols --
+  // a whole number of ranges)
+  const unsigned total = (unsigned)n_col_tiles * (unsigned)units_stride;
   unsigned gpos = (unsigned)bid * (unsigned)units_per_wg;
   unsigned gend = gpos + (unsigned)units_per_wg;
   if (gend > total) gend = total;
   while (gpos < gend) {
-  const int ct = (int)(gpos / (unsigned)units_total);
-  const int u_beg = (int)(gpos - (unsigned)ct * (unsigned)units_total);
+  const int ct = (int)(gpos / (unsigned)units_stride);
+  const int u_beg = (int)(gpos - (unsigned)ct * (unsigned)units_stride);
+  if (u_beg >= units_total) { gpos = (unsigned)(ct + 1) * (unsigned)units_stride; continue; }  // (padding behind a tile's last range)
   int u_end = units_total;
   if ((unsigned)(u_end - u_beg) > gend - gpos) u_end = u_beg + (int)(gend - gpos);
   gpos += (unsigned)(u_end - u_beg);
+  if (u_end == units_total) gpos = (unsigned)(ct + 1) * (unsigned)units_stride;  // skip the padding
   const int col0 = ct * kTileN;
 
   // ---- codebook loads (staged row-wise exactly as in dense_role) ----
@@ -869,7 +873,8 @@ sqllm_fused_batched(const float* x, const GroupArgs ga) {
   const KernelGeom& gm = sg.gm;
   const int m0 = blockIdx.y * 16 * MB;
   dense_role_mfma<BITS, MB, WAVES>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, gm.batch, m0,
-                                   (int)blockIdx.x, gm.col_tiles, gm.units_total, gm.units_per_wg, lds);
+                                   (int)blockIdx.x, gm.col_tiles, gm.units_total, gm.units_per_wg,
+                                   gm.dense_blocks == gm.col_tiles * gm.k_slices ? gm.k_slices * gm.units_per_wg : gm.units_total, lds);
 }
 
 // The sparse terms of a wide-batch op, as a launch of their own: inside the matrix-core kernel the
