@@ -53,8 +53,12 @@ __device__ __forceinline__ void xt_walk(const int* st, const float* __restrict__
 //            sample intervals that contain the chunk's first and last non-zero;
 //   round 2: the x gather (needs cols) + the row pointers of every row between those two
 //            intervals, staged straight into LDS (needs the counts);
-//   then, LDS only: each non-zero finds its row by binary search in the staged pointers, products
-//   are summed per row in LDS, and each touched row leaves as one atomic.
+//   then, LDS and registers only: the row searches of a lane's non-zeros run in lockstep in the staged
+//   pointers; a lane holds a RUN of consecutive non-zeros, folds its own products and the wave sums the
+//   lanes' open row segments with one DPP segmented scan per batch row; each row segment leaves with an
+//   LDS add from the lane that holds its last non-zero, and each touched row as one global atomic.
+//   (Wide batches read a transposed copy of vec instead -- lane = batch row, xt_walk above or the scalar
+//   walk inside.)
 // ------------------------------------------------------------------------------------------------
 template <int T, int BT, typename XT, typename AT, bool XTMODE = false>
 __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
