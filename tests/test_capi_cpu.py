@@ -305,3 +305,37 @@ def test_product_library_carries_no_measurement_variants():
         assert r.returncode != 0 and "SQLLM_ABLATION_BUILD" in r.stderr
     with pytest.raises(ValueError):
         B.build_ablation(out=B.LIB_PATH)
+
+
+def test_range_plans_cover_every_unit_exactly_once():
+    """The column-lane and matrix-core kernels cut the flattened (column tile, unit) space into ranges: contiguous
+    ones (the last may be short) or -- where a whole number per tile fits -- tile-aligned ones (the last of every
+    tile may be short; the kernels tell the two apart by dense_blocks == col_tiles * k_slices).  Either way the
+    ranges must cover all units and no range may start beyond the end."""
+    from squeezellm_amd import _lib
+
+    _lib.set_option("cu_count", 256)
+    try:
+        _lib.set_option("cols_min_batch", 1)
+        _lib.set_option("cols_max_batch", 16)  # explicit: every shape below 17 rows plans the column-lane kernel
+        seen_aligned = seen_flat = 0
+        for bits in (3, 4):
+            for K, N in ((4096, 4096), (5120, 5120), (5120, 13824), (13824, 5120), (11008, 4096), (4096, 11008), (8192, 8192),
+                         (8192, 22016), (22016, 8192), (1024, 776), (96, 68), (32, 4)):
+                if K % 32:
+                    continue
+                for batch in (2, 4, 8, 16, 17, 64, 300, 2048):  # 17+ (and 4-bit 9+ without the options): matrix cores
+                    p = _lib.plan_query(bits, K, N, batch=batch)
+                    U = K // (8 if bits == 4 else 32)
+                    upw, blocks, tiles, ks = p["groups_per_wave"], p["dense_blocks"], p["col_tiles"], p["k_slices"]
+                    assert upw >= 1 and blocks >= 1
+                    if blocks == tiles * ks:  # tile-aligned (or a contiguous cut that happens to be)
+                        assert ks * upw >= U > (ks - 1) * upw, (bits, K, N, batch, p)
+                        seen_aligned += 1
+                    else:
+                        assert blocks * upw >= tiles * U > (blocks - 1) * upw, (bits, K, N, batch, p)
+                        seen_flat += 1
+        assert seen_aligned > 20 and seen_flat > 20
+    finally:
+        _lib.set_option("cols_min_batch", 0)
+        _lib.set_option("cols_max_batch", 0)
