@@ -20,11 +20,11 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_NAME = "libsqllm_hip.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
-SOURCES = ["sqllm_kernels.hip", "sqllm_capi.hip"]
+SOURCES = ["sqllm_kernels.hip", "sqllm_pass.hip", "sqllm_capi.hip"]
 # measured-and-not-adopted kernels (round 3: the streaming batch-1 kernel, the column-pair-table kernel): part of the
 # MEASUREMENT library only, selected there with the options "stream" / "pair4"
 EXPERIMENT_SOURCES = ["sqllm_stream.hip", "sqllm_pair.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("sqllm_kernels.h", "sqllm_decode.h", "sqllm_roles.h")] + [os.path.join(INCLUDE, "sqllm_hip.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("sqllm_kernels.h", "sqllm_decode.h", "sqllm_roles.h", "sqllm_pass.h")] + [os.path.join(INCLUDE, "sqllm_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

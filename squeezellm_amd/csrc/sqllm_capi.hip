@@ -8,8 +8,11 @@
 
 #include <atomic>
 
+#include <vector>
+
 #include "sqllm_hip.h"
 #include "sqllm_kernels.h"
+#include "sqllm_pass.h"
 
 namespace {
 
@@ -39,6 +42,10 @@ struct Knobs {
   std::atomic<int> pair4_min_mb{12};   // ... from this many MB of packed weights per launch (below it the fused kernel's small tables win)
   std::atomic<int> stream{-1};         // batch-1 operator launches on the streaming kernel: -1 = default (off), 0 / 1
   std::atomic<void*> timeline{nullptr};  // measurement build: per-workgroup timestamp buffer
+  // dependency-gated pass (sqllm_pass.hip)
+  std::atomic<int> pass_poll_sleep{4};     // s_sleep(2) units between two polls of a gate
+  std::atomic<int> pass_timeout_ms{2000};  // a gate that stays shut this long ends the launch with status 1
+  std::atomic<int> pass_wgs_per_cu{0};     // resident workgroups per CU (0 = the occupancy query's answer)
 };
 constexpr int kMaxDevices = 32;
 Knobs g_knobs[kMaxDevices];
@@ -414,6 +421,7 @@ const char* sqllm_error_string(int code) {
     case SQLLM_E_BATCH: return "bad batch / vec_height";
     case SQLLM_E_OPTION: return "unknown option or bad value";
     case SQLLM_E_GROUP: return "ops of a group must share vec, K, bits and batch (1..4 ops per group)";
+    case SQLLM_E_WORKSPACE: return "pass workspace too small, misaligned, or not the one the pass was built for";
     default: break;
   }
   if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
@@ -445,6 +453,9 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "sparse_transpose")) { knobs().sparse_transpose.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "scratch_in_capture")) { knobs().scratch_in_capture.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { knobs().validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
+  if (!strcmp(name, "pass_poll_sleep")) { knobs().pass_poll_sleep.store(value); return SQLLM_OK; }
+  if (!strcmp(name, "pass_timeout_ms")) { knobs().pass_timeout_ms.store(value > 0 ? value : 1); return SQLLM_OK; }
+  if (!strcmp(name, "pass_wgs_per_cu")) { knobs().pass_wgs_per_cu.store(value); return SQLLM_OK; }
 #ifdef SQLLM_ABLATION_BUILD
   // the measured-and-not-adopted kernels (sqllm_stream.hip, sqllm_pair.hip) exist in the measurement library only
   if (!strcmp(name, "stream")) { knobs().stream.store(value > 1 ? -1 : value); return SQLLM_OK; }  // 0 off, 1 on, 2 default (off)
@@ -470,6 +481,9 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "sparse_transpose")) { *value = knobs().sparse_transpose.load(); return SQLLM_OK; }
   if (!strcmp(name, "scratch_in_capture")) { *value = knobs().scratch_in_capture.load(); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { *value = knobs().validate_csr.load(); return SQLLM_OK; }
+  if (!strcmp(name, "pass_poll_sleep")) { *value = knobs().pass_poll_sleep.load(); return SQLLM_OK; }
+  if (!strcmp(name, "pass_timeout_ms")) { *value = knobs().pass_timeout_ms.load(); return SQLLM_OK; }
+  if (!strcmp(name, "pass_wgs_per_cu")) { *value = knobs().pass_wgs_per_cu.load(); return SQLLM_OK; }
 #ifdef SQLLM_ABLATION_BUILD
   if (!strcmp(name, "stream")) { const int v = knobs().stream.load(); *value = v < 0 ? 2 : v; return SQLLM_OK; }
   if (!strcmp(name, "pair4")) { const int v = knobs().pair4.load(); *value = v < 0 ? 2 : v; return SQLLM_OK; }
@@ -848,6 +862,224 @@ int sqllm_profile_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t st
   for (int32_t i = 0; i < n_ops; ++i) ones[i] = 1;
   int rc = sqllm_profile_groups(ops, ones, n_ops, stream, reps, avg_us);
   delete[] ones;
+  return rc;
+}
+
+// ---- dependency-gated pass (sqllm_pass.hip) ------------------------------------------------------
+// Workspace image:  [status words | arrival shards, kPassGroupStride dwords per group]  <- zeroed before every launch
+//                   [PassArgs, 128 bytes] [PassSeg per op, 128-byte aligned] [PassItem per work item]
+namespace {
+
+struct PassLayout {
+  int64_t state_bytes, segs_offset, items_offset, total_bytes;
+  int32_t n_ops, n_items;
+};
+
+int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// shapes only: counts the work items and lays the workspace out (no pointer is dereferenced or stored)
+int pass_layout(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups, PassLayout* out) {
+  if (n_groups < 1 || !ops || !group_sizes) return SQLLM_E_NULL;
+  int64_t n_ops = 0, n_items = 0;
+  for (int32_t g = 0; g < n_groups; ++g) {
+    const int n = group_sizes[g];
+    if (n < 1 || n > SQLLM_PASS_MAX_GROUP_OPS) return SQLLM_E_GROUP;
+    for (int i = 0; i < n; ++i) {
+      const sqllm_op* op = &ops[n_ops + i];
+      if (op->bits != 3 && op->bits != 4) return SQLLM_E_BITS;
+      if (op->K <= 0 || op->N <= 0 || (op->K % 32) != 0 || (op->N % 4) != 0) return SQLLM_E_SHAPE;
+      if (op->batch > 1 || op->batch < 0) return SQLLM_E_BATCH;
+      sqllm::KernelGeom gm;
+      make_plan(op, &gm, n);
+      n_items += (int64_t)gm.dense_blocks + gm.csr_blocks + gm.topx_blocks;
+    }
+    n_ops += n;
+  }
+  if (n_ops >= (1 << 24) || n_items > 0x7fffffff) return SQLLM_E_SHAPE;
+  out->n_ops = (int32_t)n_ops;
+  out->n_items = (int32_t)n_items;
+  out->state_bytes = align_up(4ll * (sqllm::kPassStatusWords + (int64_t)n_groups * sqllm::kPassGroupStride), 128);
+  out->segs_offset = out->state_bytes + 128;  // (the kernel's argument block sits in between)
+  out->items_offset = align_up(out->segs_offset + (int64_t)sizeof(sqllm::PassSeg) * n_ops, 128);
+  out->total_bytes = align_up(out->items_offset + (int64_t)sizeof(sqllm::PassItem) * n_items, 128);
+  return SQLLM_OK;
+}
+
+}  // namespace
+
+int64_t sqllm_pass_workspace_bytes(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups) {
+  PassLayout lay;
+  const int rc = pass_layout(ops, group_sizes, n_groups, &lay);
+  return rc == SQLLM_OK ? lay.total_bytes : (int64_t)rc;
+}
+
+int sqllm_pass_plan(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups, void* workspace,
+                    int64_t workspace_bytes, void* host_image, sqllm_pass* pass) {
+  if (!pass || !host_image || !workspace) return SQLLM_E_NULL;
+  PassLayout lay;
+  int rc = pass_layout(ops, group_sizes, n_groups, &lay);
+  if (rc != SQLLM_OK) return rc;
+  if (workspace_bytes < lay.total_bytes || (reinterpret_cast<uintptr_t>(workspace) & 127u) != 0) return SQLLM_E_WORKSPACE;
+  char* img = static_cast<char*>(host_image);
+  memset(img, 0, (size_t)lay.total_bytes);
+  char* dev = static_cast<char*>(workspace);
+  auto* segs = reinterpret_cast<sqllm::PassSeg*>(img + lay.segs_offset);
+  auto* items = reinterpret_cast<sqllm::PassItem*>(img + lay.items_offset);
+  auto arrive_of = [&](int g) {
+    return reinterpret_cast<unsigned*>(dev) + sqllm::kPassStatusWords + (size_t)g * sqllm::kPassGroupStride;
+  };
+  const int bits = ops[0].bits;
+  int op0 = 0, n_item = 0, prev_total = 0;
+  for (int32_t g = 0; g < n_groups; ++g) {
+    const int n = group_sizes[g];
+    const int first_item = n_item;
+    sqllm::KernelGeom gm[SQLLM_PASS_MAX_GROUP_OPS];
+    for (int i = 0; i < n; ++i) {
+      const sqllm_op* op = &ops[op0 + i];
+      rc = validate(op);
+      if (rc != SQLLM_OK) return rc;
+      if (op->bits != bits) return SQLLM_E_GROUP;  // one kernel instantiation serves the whole pass
+      if (op->vec != ops[op0].vec || op->K != ops[op0].K) return SQLLM_E_GROUP;
+      make_plan(op, &gm[i], n);
+      sqllm::PassSeg& sg = segs[op0 + i];
+      sg.hot.q = reinterpret_cast<const uint32_t*>(op->qweight);
+      sg.hot.y = op->mul;
+      sg.hot.lut = op->lookup_table;
+      sg.hot.x = op->vec;
+      sg.hot.arrive = arrive_of(g);
+      // group g + 1 reads what group g wrote: its vec is gated on the completion of group g (the first group's vec
+      // is complete before the launch, by stream order)
+      sg.hot.gate_group = g > 0 ? g - 1 : -1;
+      sg.hot.gate_total = prev_total;
+      sg.hot.K = op->K;
+      sg.hot.N = op->N;
+      sg.sp.rows = gm[i].csr_blocks ? op->rows : nullptr;
+      sg.sp.cols = gm[i].csr_blocks ? op->cols : nullptr;
+      sg.sp.vals = gm[i].csr_blocks ? op->vals : nullptr;
+      sg.sp.full_rows = gm[i].topx_blocks ? op->full_rows : nullptr;
+      sg.sp.full_idx = gm[i].topx_blocks ? op->full_row_indices : nullptr;
+      sg.sp.nnz = gm[i].nnz;
+      sg.sp.topX = gm[i].topX;
+      sg.sp.col_tiles = gm[i].col_tiles;
+      sg.sp.units_total = gm[i].units_total;
+      sg.sp.units_per_wg = gm[i].units_per_wg;
+      sg.sp.group = g;
+    }
+    // a group's items in the order they are dealt: the latency-bound sparse items first (CSR chunks, top-X slabs),
+    // then the dense tiles, K slice by K slice (consecutive workgroups = consecutive column tiles, as in the
+    // one-launch-per-group kernel)
+    for (int i = 0; i < n; ++i)
+      for (int b = 0; b < gm[i].csr_blocks; ++b) items[n_item++] = {(op0 + i) | (sqllm::kPassCsr << 24), b, 0, 0};
+    for (int i = 0; i < n; ++i)
+      for (int b = 0; b < gm[i].topx_blocks; ++b) items[n_item++] = {(op0 + i) | (sqllm::kPassTopx << 24), b, 0, 0};
+    for (int i = 0; i < n; ++i)
+      for (int ks = 0; ks < gm[i].k_slices; ++ks) {
+        const int u_beg = ks * gm[i].units_per_wg;
+        const int u_end = u_beg + gm[i].units_per_wg < gm[i].units_total ? u_beg + gm[i].units_per_wg : gm[i].units_total;
+        for (int ct = 0; ct < gm[i].col_tiles; ++ct)
+          items[n_item++] = {(op0 + i) | (sqllm::kPassDense << 24), ct * sqllm::kTileN, u_beg, u_end};
+      }
+    prev_total = n_item - first_item;
+    op0 += n;
+  }
+  if (n_item != lay.n_items) return SQLLM_E_SHAPE;  // (cannot happen: pass_layout counted with the same plans)
+  {
+    sqllm::PassArgs* a = reinterpret_cast<sqllm::PassArgs*>(img + lay.state_bytes);
+    a->items = reinterpret_cast<const sqllm::PassItem*>(dev + lay.items_offset);
+    a->segs = reinterpret_cast<const sqllm::PassSeg*>(dev + lay.segs_offset);
+    a->status = reinterpret_cast<unsigned*>(dev);
+    a->n_items = lay.n_items;
+    a->poll_sleep = knobs().pass_poll_sleep.load(std::memory_order_relaxed);
+    const long long ticks = (long long)knobs().pass_timeout_ms.load(std::memory_order_relaxed) * 100000ll;  // 100 MHz
+    a->timeout_ticks = ticks > 0xffffffffll ? 0xffffffffu : (unsigned)ticks;
+  }
+  memset(pass, 0, sizeof(*pass));
+  pass->workspace = workspace;
+  pass->workspace_bytes = lay.total_bytes;
+  pass->segs_offset = lay.segs_offset;
+  pass->items_offset = lay.items_offset;
+  pass->state_bytes = (int32_t)lay.state_bytes;
+  pass->bits = bits;
+  pass->n_groups = n_groups;
+  pass->n_ops = lay.n_ops;
+  pass->n_items = lay.n_items;
+  int per_cu = knobs().pass_wgs_per_cu.load(std::memory_order_relaxed);
+  if (per_cu <= 0) {
+    per_cu = sqllm::pass_blocks_per_cu(bits);
+    if (per_cu <= 0) per_cu = 4;  // (no device to ask: the kernel is built for four per CU -- tests/test_codegen_cpu.py)
+  }
+  long long grid = (long long)per_cu * cu_count();
+  if (grid > lay.n_items) grid = lay.n_items;
+  pass->grid = (int32_t)grid;
+  pass->poll_sleep = knobs().pass_poll_sleep.load(std::memory_order_relaxed);
+  pass->timeout_ms = knobs().pass_timeout_ms.load(std::memory_order_relaxed);
+  return SQLLM_OK;
+}
+
+int sqllm_pass_build(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups, void* workspace,
+                     int64_t workspace_bytes, sqllm_pass* pass) {
+  const int64_t need = sqllm_pass_workspace_bytes(ops, group_sizes, n_groups);
+  if (need < 0) return (int)need;
+  if (workspace_bytes < need) return SQLLM_E_WORKSPACE;
+  std::vector<char> img((size_t)need);
+  int rc = sqllm_pass_plan(ops, group_sizes, n_groups, workspace, workspace_bytes, img.data(), pass);
+  if (rc != SQLLM_OK) return rc;
+  for (int i = 0; i < pass->n_ops; ++i) {
+    rc = validate_csr_values(&ops[i], nullptr);
+    if (rc != SQLLM_OK) return rc;
+  }
+  const hipError_t e = hipMemcpy(workspace, img.data(), (size_t)need, hipMemcpyHostToDevice);
+  return e == hipSuccess ? SQLLM_OK : (int)e;
+}
+
+static int pass_launch_with_events(const sqllm_pass* pass, sqllm_stream_t stream, hipEvent_t e0, hipEvent_t e1) {
+  if (!pass || !pass->workspace) return SQLLM_E_NULL;
+  if (pass->n_items < 1 || pass->grid < 1 || pass->state_bytes < 4 * sqllm::kPassStatusWords || pass->segs_offset != pass->state_bytes + 128 ||
+      pass->items_offset + (int64_t)sizeof(sqllm::PassItem) * pass->n_items > pass->workspace_bytes)
+    return SQLLM_E_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  char* ws = static_cast<char*>(pass->workspace);
+  hipError_t e = hipMemsetAsync(ws, 0, (size_t)pass->state_bytes, s);
+  if (e != hipSuccess) return (int)e;
+  return (int)sqllm::launch_pass(pass->bits, reinterpret_cast<const sqllm::PassArgs*>(ws + pass->state_bytes), pass->grid, s, e0, e1);
+}
+
+int sqllm_pass_launch(const sqllm_pass* pass, sqllm_stream_t stream) { return pass_launch_with_events(pass, stream, nullptr, nullptr); }
+
+int sqllm_pass_status(const sqllm_pass* pass, sqllm_stream_t stream, int32_t* error, int32_t* item) {
+  if (!pass || !pass->workspace) return SQLLM_E_NULL;
+  hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return (int)e;
+  unsigned st[2] = {0, 0};
+  e = hipMemcpy(st, pass->workspace, sizeof(st), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return (int)e;
+  if (error) *error = (int32_t)st[sqllm::kPassStatusError];
+  if (item) *item = (int32_t)st[sqllm::kPassStatusItem];
+  return SQLLM_OK;
+}
+
+int sqllm_pass_profile(const sqllm_pass* pass, sqllm_stream_t stream, int32_t reps, float* avg_us) {
+  if (!pass || !avg_us || reps < 1) return SQLLM_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    if (e0) (void)hipEventDestroy(e0);
+    return (int)hipGetLastError();
+  }
+  int rc = SQLLM_OK;
+  double sum = 0.0;
+  for (int r = 0; r < reps && rc == SQLLM_OK; ++r) {
+    rc = pass_launch_with_events(pass, stream, e0, e1);
+    if (rc != SQLLM_OK) break;
+    hipError_t e = hipStreamSynchronize(s);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e != hipSuccess) { rc = (int)e; break; }
+    sum += ms * 1000.0;
+  }
+  *avg_us = (float)(sum / reps);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return rc;
 }
 

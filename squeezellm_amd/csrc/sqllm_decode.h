@@ -522,6 +522,20 @@ __device__ __forceinline__ void acc_add(u64* p, float v) {
   __hip_atomic_fetch_add(SQLLM_GLOBAL(u64, p), to_fixed(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// vec element load.  COH (dependency-gated pass, sqllm_pass.hip): the element may have been produced by ANOTHER
+// workgroup of the same launch -- with device-scope atomics, performed at the memory side -- so it is read with an
+// agent-scope (sc1) load, which is never served from this CU's L1; paired with the producers' atomics and the
+// arrival counter this needs no fence on either side (MI355X_MICROARCH.md, "Valid forms": agent atomics both sides).
+template <bool COH, typename XT>
+__device__ __forceinline__ float ld_x(const XT* p) {
+  if constexpr (COH) {
+    static_assert(std::is_same<XT, float>::value, "the gated pass runs the fp32 operator ABI");
+    return __hip_atomic_load(SQLLM_GLOBAL(const float, p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    return (float)*p;
+  }
+}
+
 // Force every field of a segment descriptor into registers HERE (an empty asm statement that names the
 // value as a scalar INPUT operand: the loads feeding it must have completed; an in/out operand would
 // also hide where a pointer came from and turn every access through it into a FLAT instruction): the

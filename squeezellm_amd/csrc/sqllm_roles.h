@@ -7,6 +7,12 @@
 
 namespace sqllm {
 
+// Hook of the dependency-gated pass (sqllm_pass.hip): called by every thread of the workgroup, once, right before the
+// role's first read of vec; the default does nothing.
+struct NoGate {
+  __device__ __forceinline__ void operator()() const {}
+};
+
 // One wave's share of a chunk in transposed-vec mode at 32 rows or fewer (see csr_role): st = the wave's WN
 // non-zeros in LDS as [column | value bits | local row] planes kCsrChunk apart; R rows per pass -> 64 / R lane
 // groups, each walking a contiguous run of WN * R / 64 non-zeros; row sums go to tile[row][local column] with an
@@ -60,15 +66,19 @@ __device__ __forceinline__ void xt_walk(const int* st, const float* __restrict__
 //   (Wide batches read a transposed copy of vec instead -- lane = batch row, xt_walk above or the scalar
 //   walk inside.)
 // ------------------------------------------------------------------------------------------------
-template <int T, int BT, typename XT, typename AT, bool XTMODE = false>
+template <int T, int BT, typename XT, typename AT, bool XTMODE = false, bool XCOH = false, typename GATE = NoGate>
 __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
                                          const int* __restrict__ rows, const int* __restrict__ cols,
                                          const float* __restrict__ vals, int nnz, int K, int N, int b0,
                                          int nb, int chunk, float* lds, const Segment* lin, int lin_or_abl_bits = 0,
                                          const float* __restrict__ xT = nullptr, int Bp = 0,
-                                         unsigned long long* tl = nullptr) {
+                                         unsigned long long* tl = nullptr, GATE gate = GATE()) {
   constexpr bool LIN = sizeof(AT) == 8;
-  const int tid = threadIdx.x;
+  int tid_ = threadIdx.x;
+  // (inside the persistent pass kernel the role runs in a loop over work items: what it derives from the thread id
+  // is recomputed per item -- hoisted out of that loop it would be live across every other role of the kernel)
+  if constexpr (XCOH) asm volatile("" : "+v"(tid_));
+  const int tid = tid_;
   const int e0 = chunk * kCsrChunk;
   int e1 = e0 + kCsrChunk;
   if (e1 > nnz) e1 = nnz;
@@ -124,8 +134,9 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
   float* sacc = lds + kCsrSpanMax;           // [kCsrSpanMax]
   // the gather goes out first: the staging loop below waits for its own loads before it stores
   float xg[EPT];
+  gate();  // (gated pass: vec is not read before the producing group is complete; cols / vals / probes are already here)
 #pragma unroll
-  for (int i = 0; i < EPT; ++i) xg[i] = XTMODE ? 0.f : (float)x[(size_t)b0 * K + col[i]];  // first batch row's gather
+  for (int i = 0; i < EPT; ++i) xg[i] = XTMODE ? 0.f : ld_x<XCOH>(x + (size_t)b0 * K + col[i]);  // first batch row's gather
   // Batch rows go through in groups of `g`: as many as have room for their n row sums each in the
   // LDS accumulator (all of them for typical chunks, which span 50-100 rows), so a batched op
   // pays the zero / accumulate / flush round and its barriers once, not once per row, and the x
@@ -325,7 +336,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
 #pragma unroll
       for (int bb = 0; bb < BT; ++bb) {
         const int bi = bs + (bb < gb ? bb : gb - 1);
-        xv[i][bb] = (bs == 0 && bb == 0) ? xg[i] : (float)x[(size_t)(b0 + bi) * K + col[i]];
+        xv[i][bb] = (bs == 0 && bb == 0) ? xg[i] : ld_x<XCOH>(x + (size_t)(b0 + bi) * K + col[i]);
 #ifdef SQLLM_ABLATION_BUILD
         if (cabl & 8) xv[i][bb] = 1.f + bb;  // measurement: no gathers
 #endif
@@ -420,12 +431,14 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
 // i.e. one contiguous slab of kTopxRows*topX floats, and streams it coalesced (the reference keeps
 // topX of 128 lanes busy with stride-topX reads, quant_cuda_kernel.cu:1113-1118).
 // ------------------------------------------------------------------------------------------------
-template <int T, typename XT, typename AT>
+template <int T, typename XT, typename AT, bool XCOH = false, typename GATE = NoGate>
 __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
                                           const float* __restrict__ full_rows,
                                           const int* __restrict__ full_idx, int topX, int K, int N,
-                                          int b0, int nb, int slab, float* lds) {
-  const int tid = threadIdx.x;
+                                          int b0, int nb, int slab, float* lds, GATE gate = GATE()) {
+  int tid_ = threadIdx.x;
+  if constexpr (XCOH) asm volatile("" : "+v"(tid_));  // (see csr_role)
+  const int tid = tid_;
   const int k0 = slab * kTopxRows;
   int k1 = k0 + kTopxRows;
   if (k1 > K) k1 = K;
@@ -451,13 +464,14 @@ __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
       frv[i] = live ? full_rows[(size_t)k * topX + c] : 0.f;
     }
     const int dst = live ? full_idx[c] : 0;
+    gate();  // (gated pass: the slab of full_rows is in registers, vec comes after the gate)
     for (int b = 0; b < nb; ++b) {
       const XT* xb = x + (size_t)(b0 + b) * K;
       float p = 0.f;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int k = k0 + krow + 32 * i;
-        p = __builtin_fmaf(frv[i], k < k1 ? (float)xb[k] : 0.f, p);
+        p = __builtin_fmaf(frv[i], k < k1 ? ld_x<XCOH>(xb + k) : 0.f, p);
       }
       p += __shfl_xor(p, 16, 64);
       p += __shfl_xor(p, 32, 64);
@@ -475,6 +489,7 @@ __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
   }
   const bool in_lds = topX <= kTopxLds;
   float* sacc = lds;
+  gate();
   for (int b = 0; b < nb; ++b) {
     const XT* xb = x + (size_t)(b0 + b) * K + k0;
     AT* yb = y + (size_t)(b0 + b) * N;
@@ -485,7 +500,7 @@ __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
     for (int e = tid; e < nel; e += T) {
       const int kk = e / topX;
       const int c = e - kk * topX;
-      const float p = fr[e] * (float)xb[kk];
+      const float p = fr[e] * ld_x<XCOH>(xb + kk);
       if (in_lds) atomicAdd(sacc + c, p); else acc_add(yb + full_idx[c], p);
     }
     if (in_lds) {
