@@ -992,6 +992,9 @@ int sqllm_pass_plan(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_g
     a->poll_sleep = knobs().pass_poll_sleep.load(std::memory_order_relaxed);
     const long long ticks = (long long)knobs().pass_timeout_ms.load(std::memory_order_relaxed) * 100000ll;  // 100 MHz
     a->timeout_ticks = ticks > 0xffffffffll ? 0xffffffffu : (unsigned)ticks;
+#ifdef SQLLM_ABLATION_BUILD
+    a->timeline = static_cast<unsigned long long*>(knobs().timeline.load(std::memory_order_relaxed));
+#endif
   }
   memset(pass, 0, sizeof(*pass));
   pass->workspace = workspace;
@@ -1008,6 +1011,7 @@ int sqllm_pass_plan(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_g
     per_cu = sqllm::pass_blocks_per_cu(bits);
     if (per_cu <= 0) per_cu = 4;  // (no device to ask: the kernel is built for four per CU -- tests/test_codegen_cpu.py)
   }
+  // (work items are taken from a queue: the grid only has to be what the chip CAN hold, not what it WILL)
   long long grid = (long long)per_cu * cu_count();
   if (grid > lay.n_items) grid = lay.n_items;
   pass->grid = (int32_t)grid;
@@ -1039,7 +1043,7 @@ static int pass_launch_with_events(const sqllm_pass* pass, sqllm_stream_t stream
     return SQLLM_E_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   char* ws = static_cast<char*>(pass->workspace);
-  hipError_t e = hipMemsetAsync(ws, 0, (size_t)pass->state_bytes, s);
+  hipError_t e = sqllm::zero_pass_state(reinterpret_cast<unsigned*>(ws), pass->state_bytes / 4, s);
   if (e != hipSuccess) return (int)e;
   return (int)sqllm::launch_pass(pass->bits, reinterpret_cast<const sqllm::PassArgs*>(ws + pass->state_bytes), pass->grid, s, e0, e1);
 }

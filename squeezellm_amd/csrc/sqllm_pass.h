@@ -57,7 +57,7 @@ struct PassItem {
 };
 
 // status words in the workspace (zeroed before every launch together with the arrival shards)
-enum PassStatus : int { kPassStatusError = 0, kPassStatusItem = 1, kPassStatusWords = 16 };
+enum PassStatus : int { kPassStatusError = 0, kPassStatusItem = 1, kPassStatusHead = 8, kPassStatusWords = 16 };  // [2..7]: diagnostics of a timeout
 
 struct PassArgs {
   const PassItem* items;
@@ -67,11 +67,13 @@ struct PassArgs {
   int poll_sleep;          // s_sleep(2) units between two polls of a gate
   unsigned timeout_ticks;  // 100 MHz ticks a gate may stay shut before the launch gives up (status[0] = 1)
   int pad;
+  unsigned long long* timeline;  // measurement builds: 4 x u64 stamps per work item (tools/pass_timeline.py); null otherwise
 };
-static_assert(sizeof(PassArgs) == 40, "read with scalar loads");
+static_assert(sizeof(PassArgs) == 48, "read with scalar loads");
 
 // `device_args`: the PassArgs block inside the workspace image
 hipError_t launch_pass(int bits, const PassArgs* device_args, int grid, hipStream_t stream, hipEvent_t e0, hipEvent_t e1);
+hipError_t zero_pass_state(unsigned* state, int words, hipStream_t stream);
 int pass_blocks_per_cu(int bits);  // resident workgroups per CU of the pass kernel (occupancy query; 0 on error)
 
 }  // namespace sqllm

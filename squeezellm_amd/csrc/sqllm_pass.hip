@@ -25,9 +25,12 @@
 // item would cost 1.7-6.5 us).  Every gate is bounded: a launch whose gate stays shut for `timeout_ticks`
 // raises status[0] and lets everything through (the results are then garbage, the launch still ends).
 //
-// Work items are dealt round-robin: workgroup w takes items w, w + grid, w + 2 grid ...; the grid is what the
-// chip holds at once (4 workgroups of 8 waves per CU: 64 VGPRs, <= 40 KB LDS), so every item below an item that
-// waits is owned by a resident workgroup that reaches it first: no gate can wait for work that has not started.
+// Work items are taken from ONE queue in pass order (a device-scope ticket per item, fetched one item ahead): only
+// workgroups that are actually running hold items, so every item below an item that waits at a gate is in the hands
+// of a running workgroup -- whatever the chip admits.  (Dealing the items round-robin over a grid "that the chip
+// holds at once" deadlocked as soon as another kernel ran beside the pass: with a second queue active the hardware
+// kept exactly three of the four workgroups per CU resident and never admitted the rest while the first ones spun --
+// profiles/r04_pass_residency.txt.)
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -55,6 +58,15 @@ __device__ __forceinline__ T ld_const(const T* p) {
   T t;
   __builtin_memcpy(&t, w, sizeof(T));
   return t;
+}
+
+// Pointers that come out of the pass tables are plain integers to the compiler: without this it cannot tell global
+// from LDS / scratch and every access through them becomes a FLAT instruction (which also drags lgkmcnt into every
+// wait on a vector load).
+template <typename T>
+__device__ __forceinline__ T* as_global(T* p) {
+  // integer -> global pointer -> generic pointer: the address-space inference pass then knows where it points
+  return (T*)reinterpret_cast<__attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p));
 }
 
 __device__ __forceinline__ unsigned ld_agent_u32(const unsigned* p) {
@@ -87,6 +99,19 @@ __device__ __forceinline__ void gate_wait(const PassArgs* ap, const unsigned* ga
       const bool late = __builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)a.timeout_ticks;
       if (late || ld_agent_u32(a.status + kPassStatusError) != 0) {
         if (late && lane == 0) {
+          // (diagnostics: what the gate looked like when the wait gave up)
+          unsigned have = 0;
+          for (int sh = 0; sh < kPassShards; ++sh) have += ld_agent_u32(gate + sh * kPassShardStride);
+          __hip_atomic_store(SQLLM_GLOBAL(unsigned, a.status + 2), have, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(SQLLM_GLOBAL(unsigned, a.status + 3), (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(SQLLM_GLOBAL(unsigned, a.status + 4), (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          unsigned fresh = 0;  // the same shards through read-modify-write atomics, which execute at the memory side
+          for (int sh = 0; sh < kPassShards; ++sh)
+            fresh += __hip_atomic_fetch_add(SQLLM_GLOBAL(unsigned, const_cast<unsigned*>(gate) + sh * kPassShardStride), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(SQLLM_GLOBAL(unsigned, a.status + 5), fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          unsigned again = 0;
+          for (int sh = 0; sh < kPassShards; ++sh) again += ld_agent_u32(gate + sh * kPassShardStride);
+          __hip_atomic_store(SQLLM_GLOBAL(unsigned, a.status + 6), again, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(SQLLM_GLOBAL(unsigned, a.status + kPassStatusItem), (unsigned)item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(SQLLM_GLOBAL(unsigned, a.status + kPassStatusError), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -154,14 +179,14 @@ __device__ __forceinline__ void dense_issue(const PassSegHot& sg, const PassItem
   const int row_stride = sg.N / 4;
   int cidx = col0 / 4 + i16;
   if (cidx > row_stride - 1) cidx = row_stride - 1;
-  const char* qbase = reinterpret_cast<const char*>(sg.q);
+  const char* qbase = as_global(reinterpret_cast<const char*>(sg.q));
   const uint32_t lane_bytes = 16u * (uint32_t)cidx;
   const uint32_t row_bytes = 16u * (uint32_t)row_stride;
   const uint32_t unit_bytes = (uint32_t)R * row_bytes;
   {
     int c = col0 + 4 * i16 + (BITS == 3 ? grp : 2 * (wave & 1) + (lane >> 5));
     if (c > sg.N - 1) c = sg.N - 1;
-    const float* src = sg.lut + (size_t)c * L;
+    const float* src = as_global(sg.lut) + (size_t)c * L;
     if constexpr (BITS == 3) {
       const f32x4 ta = *reinterpret_cast<const f32x4*>(src), tb4 = *reinterpret_cast<const f32x4*>(src + 4);
       ev[0] = ta.x; ev[1] = ta.y; ev[2] = ta.z; ev[3] = ta.w;
@@ -183,17 +208,6 @@ __device__ __forceinline__ void dense_issue(const PassSegHot& sg, const PassItem
   }
 }
 
-// nothing prefetched: constants, so that the registers are not live across whatever comes next
-template <int BITS>
-__device__ __forceinline__ void dense_issue_none(u32x4 (&w0)[PassFmt<BITS>::kNbuf][Fmt<BITS>::kRows], float (&ev)[PassFmt<BITS>::kNe]) {
-#pragma unroll
-  for (int s = 0; s < PassFmt<BITS>::kNbuf; ++s)
-#pragma unroll
-    for (int r = 0; r < Fmt<BITS>::kRows; ++r) w0[s][r] = u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-  for (int i = 0; i < PassFmt<BITS>::kNe; ++i) ev[i] = 0.f;
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -206,26 +220,31 @@ __global__ void __launch_bounds__(kPassWaves * 64, 8) sqllm_pass_kernel(const Pa
   constexpr int R = F::kRows, NBUF = P::kNbuf, NXR = P::kNxr, NE = P::kNe;
   constexpr int T = kPassWaves * 64;
   constexpr int kLds = pass_lds_floats<BITS>();
-  __shared__ __attribute__((aligned(16))) float lds[kLds + 4];  // + the epilogue ticket, which no role overwrites
+  __shared__ __attribute__((aligned(16))) float lds[kLds + 4];  // + the epilogue ticket and the next-item slot, which no role overwrites
   unsigned* ticket = reinterpret_cast<unsigned*>(lds + kLds);
   if (threadIdx.x == 0) *ticket = 0u;
   const PassItem* const items = ld_const(&ap->items);
   const PassSeg* const segs = ld_const(&ap->segs);
   const int n_items = ld_const(&ap->n_items);
+#ifdef SQLLM_ABLATION_BUILD
+  unsigned long long* const tl = ld_const(&ap->timeline);
+#define SQLLM_PASS_STAMP(I, COND) if (tl && (COND)) tl[4ull * (unsigned)it + (I)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define SQLLM_PASS_STAMP(I, COND)
+#endif
 
-  int it = blockIdx.x;
+  // work items come from one queue in pass order: a ticket per item, taken one item ahead by thread 0 and handed
+  // to the workgroup through LDS (slot kLds + 1) behind the barriers the item has anyway
+  unsigned* const head = ld_const(&ap->status) + kPassStatusHead;
+  unsigned* next_slot = reinterpret_cast<unsigned*>(lds + kLds + 1);
+  if (threadIdx.x == 0) *next_slot = __hip_atomic_fetch_add(SQLLM_GLOBAL(unsigned, head), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  int it = __builtin_amdgcn_readfirstlane((int)*next_slot);
   if (it >= n_items) return;
   int open_upto = -1;  // highest group this workgroup has seen complete (a workgroup's items come in pass order)
   PassItem item = ld_const(items + it);
   PassSegHot sg = ld_const(&segs[item.seg_role & 0xffffff].hot);
   asm volatile("" ::SQLLM_PASS_HOT_OPERANDS(sg), SQLLM_PASS_ITEM_OPERANDS(item));
-  u32x4 w0[NBUF][R];
-  float ev[NE];
-  {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if ((item.seg_role >> 24) == kPassDense) dense_issue<BITS>(sg, item, lane, wave, w0, ev);
-    else dense_issue_none<BITS>(w0, ev);
-  }
 
   for (;;) {
     // per-lane constants are re-derived per item from a laundered thread id: hoisted out of the loop they would be
@@ -237,8 +256,8 @@ __global__ void __launch_bounds__(kPassWaves * 64, 8) sqllm_pass_kernel(const Pa
     const int i16 = lane & 15, grp = lane >> 4;
     const int role = item.seg_role >> 24;
     const int seg_index = item.seg_role & 0xffffff;
-    const int nit = it + (int)gridDim.x;
-    const bool more = nit < n_items;
+    int nit;
+    bool more;
     const bool shut = sg.gate_group > open_upto;
     unsigned* const my_arrive = sg.arrive;
     const unsigned* const gate = sg.arrive - kPassGroupStride;
@@ -253,7 +272,7 @@ __global__ void __launch_bounds__(kPassWaves * 64, 8) sqllm_pass_kernel(const Pa
       const int row_stride = N / 4;
       int cidx = col0 / 4 + i16;
       if (cidx > row_stride - 1) cidx = row_stride - 1;
-      const char* qbase = reinterpret_cast<const char*>(sg.q);
+      const char* qbase = as_global(reinterpret_cast<const char*>(sg.q));
       const char* xbase = reinterpret_cast<const char*>(sg.x);
       float* const y = sg.y;
       const uint32_t lane_bytes = 16u * (uint32_t)cidx;
@@ -262,12 +281,18 @@ __global__ void __launch_bounds__(kPassWaves * 64, 8) sqllm_pass_kernel(const Pa
 
       __syncthreads();  // A: every wave is done with the previous item's codebooks, its combine has read the slabs
 
-      // the next item's descriptor: fetched here, where the wave waits for this item's codebook values anyway
-      if (more) {
-        item = ld_const(items + nit);
-        sg = ld_const(&segs[item.seg_role & 0xffffff].hot);
-        asm volatile("" ::SQLLM_PASS_HOT_OPERANDS(sg), SQLLM_PASS_ITEM_OPERANDS(item));
-      }
+      // ---- run ahead of the gate: this item's codebook values and first chunk of weights.  (Issued HERE, not
+      // beside the previous item's epilogue: the whole chip finishes a group at once, and an arrival that waits
+      // behind 32 MB of everybody's prefetch delays every group by the time that burst takes -- measured: 28 us per
+      // group instead of ~6, profiles/r04_pass_first_run.txt.) ----
+      u32x4 w0[NBUF][R];
+      float ev[NE];
+      SQLLM_PASS_STAMP(0, threadIdx.x == 0)  // item begun: prefetch goes out
+      dense_issue<BITS>(sg, item, lane, wave, w0, ev);
+
+      // the ticket of the NEXT item goes out now; its round trip hides behind the codebook / gate wait
+      unsigned ticket_next = 0;
+      if (threadIdx.x == 0) ticket_next = __hip_atomic_fetch_add(SQLLM_GLOBAL(unsigned, head), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
       // ---- stage the codebooks (row-wise: sqllm_kernels.hip, dense_role) ----
       if constexpr (BITS == 3) {
@@ -281,7 +306,9 @@ __global__ void __launch_bounds__(kPassWaves * 64, 8) sqllm_pass_kernel(const Pa
       }
       // ---- the gate: vec is first consumed below ----
       if (shut && wave == 0) gate_wait(ap, gate, gate_total, it, lane);
-      __syncthreads();  // B: codebooks visible, gate open
+      if (threadIdx.x == 0) *next_slot = ticket_next;
+      __syncthreads();  // B: codebooks visible, gate open, next ticket in its slot
+      SQLLM_PASS_STAMP(1, threadIdx.x == 0)  // gate passed
       if (shut) open_upto = gate_group;
 
       f32x2 acc[2][1] = {{f32x2{0.f, 0.f}}, {f32x2{0.f, 0.f}}};
@@ -341,6 +368,14 @@ __global__ void __launch_bounds__(kPassWaves * 64, 8) sqllm_pass_kernel(const Pa
       {
         float x0[NXR][1];
         load_x(u_wave, x0);
+        // the next item's descriptor: fetched while the first x values are on their way
+        nit = __builtin_amdgcn_readfirstlane((int)*next_slot);
+        more = nit < n_items;
+        if (more) {
+          item = ld_const(items + nit);
+          sg = ld_const(&segs[item.seg_role & 0xffffff].hot);
+          asm volatile("" ::SQLLM_PASS_HOT_OPERANDS(sg), SQLLM_PASS_ITEM_OPERANDS(item));
+        }
         __builtin_amdgcn_sched_barrier(0);
         decode_chunk(u_wave, w0, x0);
       }
@@ -357,6 +392,7 @@ __global__ void __launch_bounds__(kPassWaves * 64, 8) sqllm_pass_kernel(const Pa
         acc[1][0] = f32x2{accp[2].x + accp[2].y, accp[3].x + accp[3].y};
       }
 
+      SQLLM_PASS_STAMP(2, threadIdx.x == 0)  // wave 0 done decoding
       // ---- epilogue, first half: fold the lane rows, park the wave's 64 partial sums in its slab ----
       float* red = lds + P::kCodebookFloats;  // [wave][64]
       {
@@ -370,11 +406,6 @@ __global__ void __launch_bounds__(kPassWaves * 64, 8) sqllm_pass_kernel(const Pa
         }
         if (grp == 0) *reinterpret_cast<f32x4*>(red + wave * kTileN + 4 * i16) = f32x4{col[0], col[1], col[2], col[3]};
       }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- run ahead: the next item's codebook values and first chunk go out before the combine ----
-      if (more && (item.seg_role >> 24) == kPassDense) dense_issue<BITS>(sg, item, lane, wave, w0, ev);
-      else dense_issue_none<BITS>(w0, ev);
-
       // ---- epilogue, second half (barrier-free: slabs + ticket): the last wave sums, one atomic per column ----
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       unsigned t = 0;
@@ -391,31 +422,35 @@ __global__ void __launch_bounds__(kPassWaves * 64, 8) sqllm_pass_kernel(const Pa
         // the item is complete once its accumulations have been acknowledged
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) arrive(my_arrive, it);
+        SQLLM_PASS_STAMP(3, lane == 0)  // accumulations acknowledged, arrival issued
       }
     } else {
       // ---- sparse item: the role's own code (sqllm_roles.h), gated where it first reads vec ----
       const PassSegSparse sp = ld_const(&segs[seg_index].sp);
-      const float* const x = sg.x;
-      float* const y = sg.y;
+      const float* const x = as_global(sg.x);
+      float* const y = as_global(sg.y);
       const int K = sg.K, N = sg.N, bid = item.bid;
       __syncthreads();  // the previous item is done with the LDS
+      unsigned ticket_next = 0;
+      if (threadIdx.x == 0) ticket_next = __hip_atomic_fetch_add(SQLLM_GLOBAL(unsigned, head), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const SparseGate g{ap, gate, gate_total, it, shut};
       if (role == kPassCsr)
-        csr_role<T, 1, float, float, false, true, SparseGate>(x, y, sp.rows, sp.cols, sp.vals, sp.nnz, K, N, 0, 1, bid, lds, nullptr, 0,
+        csr_role<T, 1, float, float, false, true, SparseGate>(x, y, as_global(sp.rows), as_global(sp.cols), as_global(sp.vals), sp.nnz, K, N, 0, 1, bid, lds, nullptr, 0,
                                                               nullptr, 0, nullptr, g);
       else
-        topx_role<T, float, float, true, SparseGate>(x, y, sp.full_rows, sp.full_idx, sp.topX, K, N, 0, 1, bid, lds, g);
+        topx_role<T, float, float, true, SparseGate>(x, y, as_global(sp.full_rows), as_global(sp.full_idx), sp.topX, K, N, 0, 1, bid, lds, g);
       if (shut) open_upto = gate_group;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its accumulations are acknowledged
+      if (threadIdx.x == 0) *next_slot = ticket_next;
       __syncthreads();
       if (threadIdx.x == 0) arrive(my_arrive, it);
+      nit = __builtin_amdgcn_readfirstlane((int)*next_slot);
+      more = nit < n_items;
       if (more) {
         item = ld_const(items + nit);
         sg = ld_const(&segs[item.seg_role & 0xffffff].hot);
         asm volatile("" ::SQLLM_PASS_HOT_OPERANDS(sg), SQLLM_PASS_ITEM_OPERANDS(item));
       }
-      if (more && (item.seg_role >> 24) == kPassDense) dense_issue<BITS>(sg, item, lane, wave, w0, ev);
-      else dense_issue_none<BITS>(w0, ev);
     }
     if (!more) break;
     it = nit;
@@ -431,6 +466,19 @@ int pass_blocks_per_cu(int bits) {
     return 0;
   }
   return n;
+}
+
+// The launch's state words (status, ticket head, arrival shards) are zeroed by a kernel of the library's own: a
+// hipMemsetAsync captured into a HIP graph wrote garbage into the region from the second replay on (ROCm 7.2,
+// 6272-byte region: the bytes that came back were device addresses -- profiles/r04_pass_graph_memset.txt).
+__global__ void __launch_bounds__(256) sqllm_pass_zero(unsigned* p, int words) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < words) p[i] = 0u;
+}
+
+hipError_t zero_pass_state(unsigned* state, int words, hipStream_t stream) {
+  hipLaunchKernelGGL(sqllm_pass_zero, dim3((words + 255) / 256), dim3(256), 0, stream, state, words);
+  return hipGetLastError();
 }
 
 hipError_t launch_pass(int bits, const PassArgs* device_args, int grid, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
