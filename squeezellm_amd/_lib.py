@@ -49,14 +49,6 @@ class SqllmPlan(ctypes.Structure):
         "col_tiles", "k_slices", "groups_per_wave", "dense_blocks", "csr_blocks", "topx_blocks", "grid_x", "grid_y")]
 
 
-class SqllmPass(ctypes.Structure):
-    """struct sqllm_pass (include/sqllm_hip.h): plain data describing a built pass workspace."""
-
-    _fields_ = [("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64), ("segs_offset", ctypes.c_int64),
-                ("items_offset", ctypes.c_int64), ("state_bytes", c_int32), ("bits", c_int32), ("n_groups", c_int32),
-                ("n_ops", c_int32), ("n_items", c_int32), ("grid", c_int32), ("poll_sleep", c_int32), ("timeout_ms", c_int32)]
-
-
 P = c_void_p  # every device pointer crosses as void*
 
 _DENSE = [P, P, P, P, c_int, c_int, P]
@@ -78,12 +70,6 @@ SIGNATURES = {
     "sqllm_linear_workspace_bytes": [POINTER(SqllmOp)],
     "sqllm_linear_f16": [POINTER(SqllmLinear), P],
     "sqllm_linear_f16_groups": [POINTER(SqllmLinear), POINTER(c_int32), c_int32, P, POINTER(c_int32)],
-    "sqllm_pass_workspace_bytes": [POINTER(SqllmOp), POINTER(c_int32), c_int32],
-    "sqllm_pass_plan": [POINTER(SqllmOp), POINTER(c_int32), c_int32, P, ctypes.c_int64, P, POINTER(SqllmPass)],
-    "sqllm_pass_build": [POINTER(SqllmOp), POINTER(c_int32), c_int32, P, ctypes.c_int64, POINTER(SqllmPass)],
-    "sqllm_pass_launch": [POINTER(SqllmPass), P],
-    "sqllm_pass_status": [POINTER(SqllmPass), P, POINTER(c_int32), POINTER(c_int32)],
-    "sqllm_pass_profile": [POINTER(SqllmPass), P, c_int32, POINTER(ctypes.c_float)],
     "sqllm_abi_version": [],
     "sqllm_error_string": [c_int],
     "sqllm_set_option": [c_char_p, c_int],
@@ -121,7 +107,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = argtypes
         fn.restype = (c_char_p if name == "sqllm_error_string" else
-                      ctypes.c_int64 if name in ("sqllm_linear_workspace_bytes", "sqllm_pass_workspace_bytes") else c_int)
+                      ctypes.c_int64 if name == "sqllm_linear_workspace_bytes" else c_int)
     if lib.sqllm_abi_version() != 1:
         raise RuntimeError(f"libsqllm_hip.so ABI {lib.sqllm_abi_version()} != 1 expected by this package")
     _lib = lib

@@ -20,11 +20,15 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_NAME = "libsqllm_hip.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
-SOURCES = ["sqllm_kernels.hip", "sqllm_pass.hip", "sqllm_capi.hip"]
-# measured-and-not-adopted kernels (round 3: the streaming batch-1 kernel, the column-pair-table kernel): part of the
-# MEASUREMENT library only, selected there with the options "stream" / "pair4"
-EXPERIMENT_SOURCES = ["sqllm_stream.hip", "sqllm_pair.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("sqllm_kernels.h", "sqllm_decode.h", "sqllm_roles.h", "sqllm_pass.h")] + [os.path.join(INCLUDE, "sqllm_hip.h")]
+SOURCES = ["sqllm_kernels.hip", "sqllm_capi.hip"]
+# measured-and-not-adopted kernels (round 3: the streaming batch-1 kernel, the column-pair-table kernel; round 4: the
+# dependency-gated persistent pass) and the host code that routes to them: csrc/experimental/, part of the MEASUREMENT
+# library only (options "stream" / "pair4", entry points sqllm_pass_*)
+EXPERIMENTAL = os.path.join(CSRC, "experimental")
+EXPERIMENT_SOURCES = ["experimental/sqllm_ablation.hip", "experimental/sqllm_stream.hip", "experimental/sqllm_pair.hip",
+                      "experimental/sqllm_pass.hip", "experimental/sqllm_experimental.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("sqllm_kernels.h", "sqllm_decode.h", "sqllm_roles.h", "sqllm_fused.h", "sqllm_host.h")] + [os.path.join(INCLUDE, "sqllm_hip.h")]
+EXPERIMENT_HEADERS = [os.path.join(EXPERIMENTAL, h) for h in ("sqllm_pass.h", "sqllm_pass_api.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
@@ -54,6 +58,14 @@ def is_stale() -> bool:
 
 ABLATION_LIB_NAME = "libsqllm_hip_ablation.so"
 ABLATION_LIB_PATH = os.path.join(HERE, ABLATION_LIB_NAME)
+
+
+def ablation_is_stale() -> bool:
+    if not os.path.exists(ABLATION_LIB_PATH):
+        return True
+    t = os.path.getmtime(ABLATION_LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + EXPERIMENT_SOURCES] + HEADERS + EXPERIMENT_HEADERS + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
 # measurement-only preprocessor switches (environment variable -> macro).  They select kernel variants that
 # are slower or deliberately WRONG (ablations); a build that sets any of them is an ablation build and can
 # only be written to libsqllm_hip_ablation.so, never to the product library.
@@ -63,7 +75,7 @@ VARIANT_ENV = ("SQLLM_PAIR3", "SQLLM_HALF_STAGES", "SQLLM_PAIR3_NOCONFLICT", "SQ
 
 
 def _compile(out: str, extra, verbose: bool, sources=None) -> str:
-    cmd = [hipcc(), f"--offload-arch={ARCH}", *FLAGS, *extra, "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
+    cmd = [hipcc(), f"--offload-arch={ARCH}", *FLAGS, *extra, "-shared", f"-I{INCLUDE}", f"-I{CSRC}", f"-I{EXPERIMENTAL}",
            *[os.path.join(CSRC, s) for s in (sources or SOURCES)], "-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -84,13 +96,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return _compile(LIB_PATH, [], verbose)
 
 
-def build_ablation(verbose: bool = False, out: str | None = None) -> str:
+def build_ablation(verbose: bool = False, out: str | None = None, force: bool = True) -> str:
     """Measurement build (ablation kernels, timeline probes, calibration kernels, and whatever variant
     switches the environment names) -> libsqllm_hip_ablation.so (or `out`, which must not be the product
     library).  Load it with SQLLM_LIB=<path>."""
     out = os.path.abspath(out or ABLATION_LIB_PATH)
     if out == os.path.abspath(LIB_PATH):
         raise ValueError("an ablation build must not overwrite the product library")
+    if not force and out == os.path.abspath(ABLATION_LIB_PATH) and not ablation_is_stale():
+        return out
     extra = ["-DSQLLM_ABLATION_BUILD"]
     for name in VARIANT_ENV:
         if os.environ.get(name):

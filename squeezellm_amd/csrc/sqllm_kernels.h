@@ -142,6 +142,7 @@ inline int batch_tile(int batch) { return batch <= 1 ? 1 : batch == 2 ? 2 : batc
 inline int mfma_row_blocks(int batch) { return batch <= 16 ? 1 : batch <= 32 ? 2 : 4; }
 
 hipError_t launch_fused(int bits, const LaunchArgs& a, hipStream_t stream);
+extern bool (*g_fused_variant)(int bits, const LaunchArgs& a, hipStream_t stream, hipError_t* err);  // measurement library hook (null in the product)
 hipError_t launch_pair4(const LaunchArgs& a, hipStream_t stream);  // 4-bit, batch 1, operator launches: column-pair tables, 16-wave workgroups
 // `ga`: the sparse roles of the launch (block0[] = prefix over csr + top-X workgroups only)
 hipError_t launch_stream(int bits, const StreamArgs& sa, const GroupArgs& ga, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,

@@ -157,11 +157,6 @@ class OpSequence:
         out = (ctypes.c_float * self.n_groups).from_buffer(out)
         return np.ctypeslib.as_array(out).astype(np.float64).copy()
 
-    def gated_pass(self) -> "GatedPass":
-        """The same groups as ONE persistent, dependency-gated launch (sqllm_pass_*): same results as launch() --
-        group g + 1 sees vec / mul as groups 0..g left them -- but only vec waits for the previous group."""
-        return GatedPass(self)
-
     def graph(self, warmup: int = 1) -> "torch.cuda.CUDAGraph":
         """Capture one pass into a HIP graph (replay with .replay())."""
         side = torch.cuda.Stream(self.device)
@@ -175,57 +170,3 @@ class OpSequence:
             self.launch()
         return g
 
-
-class GatedPass:
-    """A decode pass as one persistent launch (include/sqllm_hip.h, "Dependency-gated pass"): the groups of an
-    OpSequence in pass order, every group gated on the completion of the one before it exactly where it first
-    reads vec.  Batch-1 operator sequences only."""
-
-    def __init__(self, seq: OpSequence):
-        if seq.linear:
-            raise ValueError("the gated pass runs the fp32 operator ABI (not the fused fp16 linear)")
-        self.seq = seq  # (keeps descriptors and tensors alive)
-        self.device = seq.device
-        self._lib = seq._lib
-        need = self._lib.sqllm_pass_workspace_bytes(seq.ops, seq._sizes, seq.n_groups)
-        if need < 0:
-            _lib.check(int(need), "sqllm_pass_workspace_bytes")
-        self.workspace = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
-        self.desc = _lib.SqllmPass()
-        with torch.cuda.device(self.device):
-            rc = self._lib.sqllm_pass_build(seq.ops, seq._sizes, seq.n_groups, self.workspace.data_ptr(), int(need), ctypes.byref(self.desc))
-        _lib.check(rc, "sqllm_pass_build")
-        self.n_items, self.grid = self.desc.n_items, self.desc.grid
-
-    def launch(self) -> None:
-        """Enqueue the pass on the current stream: one memset node + one kernel."""
-        rc = self._lib.sqllm_pass_launch(ctypes.byref(self.desc), torch.cuda.current_stream(self.device).cuda_stream)
-        if rc != 0:
-            _lib.check(rc, "sqllm_pass_launch")
-
-    def status(self):
-        """(error, item) of the last launch; synchronises the current stream.  error 0 = every gate opened."""
-        err, item = ctypes.c_int32(0), ctypes.c_int32(0)
-        rc = self._lib.sqllm_pass_status(ctypes.byref(self.desc), torch.cuda.current_stream(self.device).cuda_stream,
-                                         ctypes.byref(err), ctypes.byref(item))
-        _lib.check(rc, "sqllm_pass_status")
-        return err.value, item.value
-
-    def profile(self, reps: int = 3) -> float:
-        """Average device-side duration of the pass kernel in microseconds (its own start / stop events)."""
-        out = ctypes.c_float(0.0)
-        rc = self._lib.sqllm_pass_profile(ctypes.byref(self.desc), torch.cuda.current_stream(self.device).cuda_stream, int(reps), ctypes.byref(out))
-        _lib.check(rc, "sqllm_pass_profile")
-        return float(out.value)
-
-    def graph(self, warmup: int = 1) -> "torch.cuda.CUDAGraph":
-        side = torch.cuda.Stream(self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self.launch()
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.launch()
-        return g

@@ -339,3 +339,17 @@ def test_range_plans_cover_every_unit_exactly_once():
     finally:
         _lib.set_option("cols_min_batch", 0)
         _lib.set_option("cols_max_batch", 0)
+
+
+def test_product_sources_carry_no_measurement_routing():
+    """The measured-and-not-adopted kernels, their options and their routing live in csrc/experimental/ (measurement
+    library) and reach the host layer through the hooks of sqllm_host.h: the product's host source has no
+    measurement-build branch at all, and the product library leaves every hook null (unknown options are rejected)."""
+    from squeezellm_amd import build as B
+
+    src = open(os.path.join(B.CSRC, "sqllm_capi.hip")).read()
+    assert "SQLLM_ABLATION_BUILD" not in src
+    assert not any(os.path.basename(s) in ("sqllm_stream.hip", "sqllm_pair.hip", "sqllm_pass.hip") for s in B.SOURCES)
+    lib = _lib.load()
+    for name in (b"stream", b"pair4", b"ablate", b"lds_pad", b"pass_poll_sleep"):
+        assert lib.sqllm_set_option(name, 1) == -7, name  # SQLLM_E_OPTION

@@ -1,5 +1,7 @@
-"""The dependency-gated pass (sqllm_pass_*, squeezellm_amd/csrc/sqllm_pass.hip): consecutive groups of a decode
-pass as ONE persistent launch, each group gated on the completion of the one before it where it first reads vec.
+"""The dependency-gated pass (sqllm_pass_*, squeezellm_amd/csrc/experimental/sqllm_pass.hip): consecutive groups of a
+decode pass as ONE persistent launch, each group gated on the completion of the one before it where it first reads
+vec.  MEASUREMENT LIBRARY: built, measured 2.3-4x slower than one launch per group (profiles/r04_pass_*.txt) and not
+adopted; these tests keep it parity-green so that the measurement stays reproducible.
 
 The tests chain the groups for real: o_proj's input IS q_proj's output buffer, gate/up read o_proj's output,
 down_proj reads gate_proj's, the next layer's q/k/v read down_proj's -- so an op that consumed its vec before the
@@ -84,13 +86,13 @@ def test_chained_pass_small_shapes(gpu, bits, sparse, topX):
     workgroups, every workgroup walks several items and most items wait at a gate."""
     import torch
 
-    from squeezellm_amd import decode
+    from squeezellm_amd import decode, experimental
 
     layers, xs, ys = _chain(SMALL, 12, bits, sparse, topX, gpu, seed0=500 + bits, scale=_flat)
     ys0 = [y.cpu().numpy().copy() for y in ys]
     seq = decode.OpSequence(layers, xs, ys, fuse_shared_input=True)
     assert seq.groups[:4] == [[0, 1, 2], [3], [4, 5], [6]]
-    p = seq.gated_pass()
+    p = experimental.GatedPass(seq)
     assert p.n_items > p.grid > 0
     p.launch()
     assert p.status() == (0, 0)
@@ -104,13 +106,13 @@ def test_chained_pass_llama7b_graph_replay(gpu, bits, sparse, topX):
     arrival counters are re-zeroed by the launch's own memset node, consumers are L1-warm from the replay before)."""
     import torch
 
-    from squeezellm_amd import decode, synth
+    from squeezellm_amd import decode, experimental, synth
 
     layers, xs, ys = _chain(synth.MODEL_SHAPES["llama-7b"]["linears"], 3, bits, sparse, topX, gpu, seed0=700 + bits, scale=_flat)
     ys0_t = [y.clone() for y in ys]
     ys0 = [y.cpu().numpy().copy() for y in ys]
     seq = decode.OpSequence(layers, xs, ys, fuse_shared_input=True)
-    p = seq.gated_pass()
+    p = experimental.GatedPass(seq)
 
     def step():
         torch._foreach_copy_(ys, ys0_t)
@@ -137,7 +139,7 @@ def test_pass_equals_grouped_launches(gpu):
     vectors (to summation order) -- including the accumulate into a non-zero mul and the in-order visibility of vec."""
     import torch
 
-    from squeezellm_amd import decode, synth
+    from squeezellm_amd import decode, experimental, synth
 
     layers, xs, ys = _chain(synth.MODEL_SHAPES["llama-7b"]["linears"], 2, 4, 0.0045, 10, gpu, seed0=900, scale=_flat)
     ys0_t = [y.clone() for y in ys]
@@ -146,7 +148,7 @@ def test_pass_equals_grouped_launches(gpu):
     torch.cuda.synchronize()
     want = [y.clone() for y in ys]
     torch._foreach_copy_(ys, ys0_t)
-    p = seq.gated_pass()
+    p = experimental.GatedPass(seq)
     p.launch()
     assert p.status() == (0, 0)
     for l, a, b in zip(layers, ys, want):
@@ -160,13 +162,13 @@ def test_pass_under_uneven_load(gpu):
     every word of every output checked."""
     import torch
 
-    from squeezellm_amd import decode
+    from squeezellm_amd import decode, experimental
 
     layers, xs, ys = _chain(SMALL, 6, 4, 0.0045, 10, gpu, seed0=1100, scale=_flat)
     ys0_t = [y.clone() for y in ys]
     ys0 = [y.cpu().numpy().copy() for y in ys]
     seq = decode.OpSequence(layers, xs, ys, fuse_shared_input=True)
-    p = seq.gated_pass()
+    p = experimental.GatedPass(seq)
     noise = torch.empty(64 << 20, device=gpu)
     side = torch.cuda.Stream(gpu)
     for r in range(6):
@@ -184,15 +186,15 @@ def test_pass_under_uneven_load(gpu):
 def test_pass_rejects_what_it_cannot_run(gpu):
     import torch
 
-    from squeezellm_amd import decode, synth
+    from squeezellm_amd import decode, experimental, synth
 
     lay = synth.make_layer(256, 128, 4, device=gpu, seed=1)
     x = torch.randn(2, 256, device=gpu)
     y = torch.zeros(2, 128, device=gpu)
     seq = decode.OpSequence([lay], [x], [y], batched=True)
     with pytest.raises(ValueError):
-        seq.gated_pass()  # batched ops are not part of a gated pass
+        experimental.GatedPass(seq)  # batched ops are not part of a gated pass
     lay3 = synth.make_layer(256, 128, 3, device=gpu, seed=2)
     seq = decode.OpSequence([lay, lay3], [x[0], x[1]], [y[0], y[1]])
     with pytest.raises(ValueError):
-        seq.gated_pass()  # one bit width per pass
+        experimental.GatedPass(seq)  # one bit width per pass

@@ -8,14 +8,14 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from squeezellm_amd import decode, synth
+from squeezellm_amd import decode, experimental, synth
 from tests import test_gpu_pass as T
 
 gpu = torch.device("cuda:0")
 layers, xs, ys = T._chain(synth.MODEL_SHAPES["llama-7b"]["linears"], 3, 4, 0.0, 0, gpu, seed0=704, scale=T._flat)
 ys0_t = [y.clone() for y in ys]
 seq = decode.OpSequence(layers, xs, ys, fuse_shared_input=True)
-p = seq.gated_pass()
+p = experimental.GatedPass(seq)
 print("items", p.n_items, "grid", p.grid, "state_bytes", p.desc.state_bytes, "ws", hex(p.workspace.data_ptr()))
 
 

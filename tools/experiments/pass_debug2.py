@@ -9,14 +9,14 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from squeezellm_amd import decode
+from squeezellm_amd import decode, experimental
 from tests import test_gpu_pass as T
 
 gpu = torch.device("cuda:0")
 layers, xs, ys = T._chain(T.SMALL, 6, 4, 0.0045, 10, gpu, seed0=1100, scale=T._flat)
 ys0_t = [y.clone() for y in ys]
 seq = decode.OpSequence(layers, xs, ys, fuse_shared_input=True)
-p = seq.gated_pass()
+p = experimental.GatedPass(seq)
 print("items", p.n_items, "grid", p.grid, "groups", seq.n_groups)
 img = p.workspace.cpu().numpy()
 items = img[p.desc.items_offset:p.desc.items_offset + 16 * p.n_items].view(np.int32).reshape(-1, 4)

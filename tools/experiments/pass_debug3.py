@@ -10,20 +10,18 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from squeezellm_amd import _lib, decode
+from squeezellm_amd import _lib, decode, experimental
 from tests import test_gpu_pass as T
 
 gpu = torch.device("cuda:0")
-lib = _lib.load()
-lib.sqllm_debug_set_timeline.argtypes = [ctypes.c_void_p]
-lib.sqllm_debug_set_timeline.restype = None
+lib = experimental.load()
 layers, xs, ys = T._chain(T.SMALL, 6, 4, 0.0, 0, gpu, seed0=1100, scale=T._flat)  # dense only: every item stamps
 ys0_t = [y.clone() for y in ys]
 seq = decode.OpSequence(layers, xs, ys, fuse_shared_input=True)
-p0 = seq.gated_pass()
+p0 = experimental.GatedPass(seq)
 buf = torch.zeros((p0.n_items, 4), dtype=torch.int64, device=gpu)
 lib.sqllm_debug_set_timeline(ctypes.c_void_p(buf.data_ptr()))
-p = seq.gated_pass()
+p = experimental.GatedPass(seq)
 lib.sqllm_debug_set_timeline(None)
 print("items", p.n_items, "grid", p.grid, "groups", seq.n_groups)
 noise = torch.empty(64 << 20, device=gpu)

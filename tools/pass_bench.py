@@ -34,7 +34,7 @@ def main():
     args = ap.parse_args()
     import torch
 
-    from squeezellm_amd import _lib, decode, synth
+    from squeezellm_amd import _lib, decode, experimental, synth
 
     dev = torch.device("cuda", 0)
     cfg = bench.CONFIGS[args.config]
@@ -64,8 +64,8 @@ def main():
 
     def run_pass(tag, **opts):
         for k, v in opts.items():
-            _lib.set_option(k, v)
-        p = seq.gated_pass()
+            experimental.set_option(k, v)
+        p = experimental.GatedPass(seq)
         gp = p.graph(warmup=1)
         med, best = timed(gp.replay, sync, args.steps)
         err = p.status()
@@ -78,16 +78,16 @@ def main():
     if args.sweep:
         for s in (1, 2, 8, 16):
             run_pass("poll_sleep", pass_poll_sleep=s)
-        _lib.set_option("pass_poll_sleep", 4)
+        experimental.set_option("pass_poll_sleep", 4)
         for w in (3, 2):
             run_pass("wgs_per_cu", pass_wgs_per_cu=w)
-        _lib.set_option("pass_wgs_per_cu", 0)
+        experimental.set_option("pass_wgs_per_cu", 0)
         for t in (256, 512, 768, 1024, 1536):
             run_pass("target_wgs", target_wgs=t)
-        _lib.set_option("target_wgs", 0)
+        experimental.set_option("target_wgs", 0)
         for gpw in (16, 32, 64):
             run_pass("groups_per_wave", groups_per_wave=gpw)
-        _lib.set_option("groups_per_wave", 0)
+        experimental.set_option("groups_per_wave", 0)
 
 
 if __name__ == "__main__":

@@ -18,7 +18,7 @@ def main():
     import numpy as np
     import torch
 
-    from squeezellm_amd import _lib, decode
+    from squeezellm_amd import _lib, decode, experimental
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="7b-w4-s0")
@@ -26,18 +26,16 @@ def main():
     ap.add_argument("--groups", type=int, default=12, help="groups to print")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    lib = _lib.load()
-    lib.sqllm_debug_set_timeline.argtypes = [ctypes.c_void_p]
-    lib.sqllm_debug_set_timeline.restype = None
+    lib = experimental.load()
     cfg = bench.CONFIGS[a.config]
     layers = bench.build_layers(cfg, dev, 0, a.layers)
     gen = torch.Generator(device=dev).manual_seed(1)
     xs, ys = bench.decoder_inputs(layers, dev, gen)
     seq = decode.OpSequence(layers, xs, ys, fuse_shared_input=True)
-    p0 = seq.gated_pass()
+    p0 = experimental.GatedPass(seq)
     buf = torch.zeros((p0.n_items, 4), dtype=torch.int64, device=dev)
     lib.sqllm_debug_set_timeline(ctypes.c_void_p(buf.data_ptr()))
-    p = seq.gated_pass()
+    p = experimental.GatedPass(seq)
     lib.sqllm_debug_set_timeline(None)
     for _ in range(3):
         p.launch()
