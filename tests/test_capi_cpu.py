@@ -345,6 +345,7 @@ def test_product_sources_carry_no_measurement_routing():
     """The measured-and-not-adopted kernels, their options and their routing live in csrc/experimental/ (measurement
     library) and reach the host layer through the hooks of sqllm_host.h: the product's host source has no
     measurement-build branch at all, and the product library leaves every hook null (unknown options are rejected)."""
+    from squeezellm_amd import _lib
     from squeezellm_amd import build as B
 
     src = open(os.path.join(B.CSRC, "sqllm_capi.hip")).read()
