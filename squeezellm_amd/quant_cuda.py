@@ -18,6 +18,8 @@ CPU / eager fallback: CPU tensors or a missing library raise.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -32,6 +34,32 @@ __all__ = [
 _F32 = torch.float32
 _I32 = torch.int32
 
+# ---------------------------------------------------------------------------------------------------
+# Host path.  The reference's wrapper is a device guard and a call (quant_cuda.cpp:112-125); this one is Python over
+# ctypes, so what a call costs on the host decides the eager decode rate (224 calls per 7B token).  Three things keep
+# it short:
+#   * the PERSISTENT operands of a layer (qweight, lookup_table, rows / cols / vals, full_rows / full_row_indices --
+#     the same tensor objects call after call) are validated once and remembered by object identity
+#     (`_persistent`): pointer, shape facts and device come out of a dict; only vec and mul, which are new tensors
+#     on every call, are checked every time;
+#   * the current stream is read as a raw handle (torch._C._cuda_getCurrentRawStream) instead of building a
+#     torch.cuda.Stream object, and the device guard is two integer compares unless vec lives on another device;
+#   * the C functions are looked up once per (bits, op kind) and kept with their prototypes.
+# Measured per call on the MI355X host (tools/host_cost.py): see DESIGN.md, "host path".
+# ---------------------------------------------------------------------------------------------------
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_get_device = torch._C._cuda_getDevice
+_set_device = torch._C._cuda_setDevice
+
+_fn_cache = {}
+
+
+def _fn(name: str):
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(_lib.load(), name)
+    return fn
+
 
 def _dev_ptr(t, dtype, name: str) -> int:
     if not isinstance(t, torch.Tensor):
@@ -45,138 +73,173 @@ def _dev_ptr(t, dtype, name: str) -> int:
     return t.data_ptr()
 
 
-def _same_device(ref: torch.Tensor, *others) -> None:
-    for t in others:
-        if t.device != ref.device:
-            raise RuntimeError(f"all operands must be on {ref.device}, found {t.device}")
+# id(tensor) -> (weakref to it, data_ptr, device index, shape) for operands that were validated once
+_persistent = {}
 
 
-class _on_device_of:
-    """`const at::cuda::OptionalCUDAGuard device_guard(device_of(vec))` (quant_cuda.cpp:116):
-    make vec's device current for the launch; a no-op in the common single-device case."""
-
-    __slots__ = ("idx", "prev")
-
-    def __init__(self, t: torch.Tensor):
-        self.idx = t.device.index
-
-    def __enter__(self):
-        self.prev = torch.cuda.current_device()
-        if self.prev != self.idx:
-            torch.cuda.set_device(self.idx)
-        return torch.cuda.current_stream(self.idx).cuda_stream
-
-    def __exit__(self, *exc):
-        if self.prev != self.idx:
-            torch.cuda.set_device(self.prev)
-        return False
+def _persist(t, dtype, name: str):
+    """(data_ptr, device index, shape) of a layer's persistent operand, validated on first sight.  The entry is
+    dropped when the tensor dies (weakref callback) and re-validated if its storage moved."""
+    e = _persistent.get(id(t))
+    if e is not None and e[0]() is t and e[1] == t.data_ptr():
+        return e
+    ptr = _dev_ptr(t, dtype, name)
+    key = id(t)
+    e = (weakref.ref(t, lambda _r, k=key: _persistent.pop(k, None)), ptr, t.get_device(), tuple(t.shape))
+    _persistent[key] = e
+    return e
 
 
-def _dense_shapes(vec, mat, mul, lookup_table, bits: int, batched: bool):
-    if mat.dim() != 2:
+def _io_type(vec, mul) -> None:
+    """vec / mul are new tensors on every call, so every call checks them -- type and dtype first (as the reference's
+    data_ptr<float>() would throw first), the rest in _io_ptr once the layer's device is known"""
+    if not isinstance(vec, torch.Tensor) or not isinstance(mul, torch.Tensor):
+        raise TypeError(f"vec and mul must be torch.Tensors, got {type(vec).__name__} and {type(mul).__name__}")
+    if vec.dtype is not _F32 or mul.dtype is not _F32:
+        raise TypeError(f"vec and mul must be {_F32}, got {vec.dtype} and {mul.dtype}")
+
+
+def _io_ptr(t, name: str, dev: int) -> int:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor (quant_cuda has no CPU path), got device {t.device}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if t.get_device() != dev:
+        raise RuntimeError(f"all operands must be on cuda:{dev}, found {name} on {t.device}")
+    return t.data_ptr()
+
+
+def _launch(fn, dev: int, args: tuple):
+    """`const at::cuda::OptionalCUDAGuard device_guard(device_of(vec))` (quant_cuda.cpp:116) + the call: vec's
+    device is made current for the launch (two integer compares when it already is), the launch goes to torch's
+    current stream of that device."""
+    prev = _get_device()
+    if prev != dev:
+        _set_device(dev)
+        try:
+            rc = fn(*args, _raw_stream(dev))
+        finally:
+            _set_device(prev)
+    else:
+        rc = fn(*args, _raw_stream(dev))
+    if rc:
+        _lib.check(rc, fn.__name__)
+
+
+def _qweight(mat, bits: int, name: str):
+    e = _persist(mat, _I32, name)
+    shape = e[3]
+    if len(shape) != 2:
         raise ValueError("qweight must be 2-D [K/32*bits, N]")
-    height, width = mat.shape
-    if height % bits:
-        raise ValueError(f"qweight has {height} rows, not a multiple of {bits}")
-    K = height // bits * 32
-    if tuple(lookup_table.shape) != (width, 1 << bits):
-        raise ValueError(f"lookup_table must be [{width}, {1 << bits}], got {tuple(lookup_table.shape)}")
+    if shape[0] % bits:
+        raise ValueError(f"qweight has {shape[0]} rows, not a multiple of {bits}")
+    return e[1], e[2], shape[0], shape[1], shape[0] // bits * 32
+
+
+def _lut(lookup_table, width: int, bits: int, dev: int) -> int:
+    e = _persist(lookup_table, _F32, "lookup_table")
+    if e[3] != (width, 1 << bits):
+        raise ValueError(f"lookup_table must be [{width}, {1 << bits}], got {e[3]}")
+    if e[2] != dev:
+        raise RuntimeError(f"all operands must be on cuda:{dev}, found lookup_table on cuda:{e[2]}")
+    return e[1]
+
+
+def _vec_mul(vec, mul, K: int, width: int, batched: bool, dev: int):
+    pv, pm = _io_ptr(vec, "vec", dev), _io_ptr(mul, "mul", dev)
     if batched:
         if vec.dim() != 2 or vec.shape[1] != K:
             raise ValueError(f"vec must be [batch, {K}], got {tuple(vec.shape)}")
-        if mul.dim() != 2 or tuple(mul.shape) != (vec.shape[0], width):
-            raise ValueError(f"mul must be [{vec.shape[0]}, {width}], got {tuple(mul.shape)}")
-        return height, width, K, vec.shape[0]
+        batch = vec.shape[0]
+        if mul.dim() != 2 or mul.shape[0] != batch or mul.shape[1] != width:
+            raise ValueError(f"mul must be [{batch}, {width}], got {tuple(mul.shape)}")
+        return pv, pm, batch
     if vec.numel() != K:
         raise ValueError(f"vec must have {K} elements, got {vec.numel()}")
     if mul.numel() != width:
         raise ValueError(f"mul must have {width} elements, got {mul.numel()}")
-    return height, width, K, 0
+    return pv, pm, 0
 
 
-def _csr_shapes(rows, cols, vals, num_rows: int, width: int) -> int:
+def _csr(rows, cols, vals, num_rows, width: int, dev: int, vals_name: str = "mat (csr values)"):
     if int(num_rows) != width:
         raise ValueError(f"num_rows ({num_rows}) must equal outfeatures ({width})")
-    if rows.numel() != width + 1:
-        raise ValueError(f"rows must have {width + 1} entries, got {rows.numel()}")
-    if cols.numel() != vals.numel():
+    er, ec, ev = _persist(rows, _I32, "rows"), _persist(cols, _I32, "cols"), _persist(vals, _F32, vals_name)
+    n_rows = 1
+    for d in er[3]:
+        n_rows *= d
+    if n_rows != width + 1:
+        raise ValueError(f"rows must have {width + 1} entries, got {n_rows}")
+    nnz = 1
+    for d in ec[3]:
+        nnz *= d
+    n_vals = 1
+    for d in ev[3]:
+        n_vals *= d
+    if nnz != n_vals:
         raise ValueError("cols and vals must have the same length")
-    return cols.numel()
+    for e, nm in ((er, "rows"), (ec, "cols"), (ev, vals_name)):
+        if e[2] != dev:
+            raise RuntimeError(f"all operands must be on cuda:{dev}, found {nm} on cuda:{e[2]}")
+    return er[1], ec[1], ev[1], nnz
+
+
+_SFX = ("", "_batched")
 
 
 def _dense(bits, batched, vec, mat, mul, lookup_table):
-    height, width, K, batch = _dense_shapes(vec, mat, mul, lookup_table, bits, batched)
-    pv, pq = _dev_ptr(vec, _F32, "vec"), _dev_ptr(mat, _I32, "mat")
-    pm, pl = _dev_ptr(mul, _F32, "mul"), _dev_ptr(lookup_table, _F32, "lookup_table")
-    _same_device(vec, mat, mul, lookup_table)
-    lib = _lib.load()
-    with _on_device_of(vec) as stream:
-        if batched:
-            fn = getattr(lib, f"sqllm_vecquant{bits}matmul_nuq_perchannel_batched")
-            rc = fn(pv, pq, pm, pl, height, width, batch, K, stream)
-        else:
-            fn = getattr(lib, f"sqllm_vecquant{bits}matmul_nuq_perchannel")
-            rc = fn(pv, pq, pm, pl, height, width, stream)
-    _lib.check(rc, fn.__name__)
+    _io_type(vec, mul)
+    pq, dev, height, width, K = _qweight(mat, bits, "mat")
+    pl = _lut(lookup_table, width, bits, dev)
+    pv, pm, batch = _vec_mul(vec, mul, K, width, batched, dev)
+    fn = _fn(f"sqllm_vecquant{bits}matmul_nuq_perchannel{_SFX[batched]}")
+    _launch(fn, dev, (pv, pq, pm, pl, height, width, batch, K) if batched else (pv, pq, pm, pl, height, width))
 
 
 def _spmv(bits, batched, rows, cols, mat, vec, mul, num_rows, matq, lookup_table):
-    height, width, K, batch = _dense_shapes(vec, matq, mul, lookup_table, bits, batched)
-    nnz = _csr_shapes(rows, cols, mat, num_rows, width)
-    pr, pc, pvl = _dev_ptr(rows, _I32, "rows"), _dev_ptr(cols, _I32, "cols"), _dev_ptr(mat, _F32, "mat (csr values)")
-    pv, pq = _dev_ptr(vec, _F32, "vec"), _dev_ptr(matq, _I32, f"mat{bits}")
-    pm, pl = _dev_ptr(mul, _F32, "mul"), _dev_ptr(lookup_table, _F32, "lookup_table")
-    _same_device(vec, rows, cols, mat, matq, mul, lookup_table)
-    lib = _lib.load()
-    with _on_device_of(vec) as stream:
-        if batched:
-            fn = getattr(lib, f"sqllm_vecquant{bits}matmul_spmv_nuq_perchannel_batched")
-            rc = fn(pr, pc, pvl, pv, pm, int(num_rows), pq, pl, height, width, nnz, batch, K, stream)
-        else:
-            fn = getattr(lib, f"sqllm_vecquant{bits}matmul_spmv_nuq_perchannel")
-            rc = fn(pr, pc, pvl, pv, pm, int(num_rows), pq, pl, height, width, nnz, stream)
-    _lib.check(rc, fn.__name__)
+    _io_type(vec, mul)
+    pq, dev, height, width, K = _qweight(matq, bits, f"mat{bits}")
+    pl = _lut(lookup_table, width, bits, dev)
+    pr, pc, pvl, nnz = _csr(rows, cols, mat, num_rows, width, dev)
+    pv, pm, batch = _vec_mul(vec, mul, K, width, batched, dev)
+    fn = _fn(f"sqllm_vecquant{bits}matmul_spmv_nuq_perchannel{_SFX[batched]}")
+    head = (pr, pc, pvl, pv, pm, int(num_rows), pq, pl, height, width, nnz)
+    _launch(fn, dev, head + (batch, K) if batched else head)
 
 
 def _hybrid(bits, batched, rows, cols, mat, vec, full_rows, full_row_indices, mul, num_rows, matq, lookup_table):
-    height, width, K, batch = _dense_shapes(vec, matq, mul, lookup_table, bits, batched)
-    nnz = _csr_shapes(rows, cols, mat, num_rows, width)
-    if full_rows.dim() != 2 or full_rows.shape[0] != K:
-        raise ValueError(f"full_rows must be [{K}, topX], got {tuple(full_rows.shape)}")
-    topX = full_rows.shape[1]
-    if full_row_indices.numel() != topX:
-        raise ValueError(f"full_row_indices must have {topX} entries, got {full_row_indices.numel()}")
-    pr, pc, pvl = _dev_ptr(rows, _I32, "rows"), _dev_ptr(cols, _I32, "cols"), _dev_ptr(mat, _F32, "mat (csr values)")
-    pv, pq = _dev_ptr(vec, _F32, "vec"), _dev_ptr(matq, _I32, f"mat{bits}")
-    pm, pl = _dev_ptr(mul, _F32, "mul"), _dev_ptr(lookup_table, _F32, "lookup_table")
-    pfr, pfi = _dev_ptr(full_rows, _F32, "full_rows"), _dev_ptr(full_row_indices, _I32, "full_row_indices")
-    _same_device(vec, rows, cols, mat, matq, mul, lookup_table, full_rows, full_row_indices)
-    lib = _lib.load()
-    with _on_device_of(vec) as stream:
-        if batched:
-            fn = getattr(lib, f"sqllm_vecquant{bits}matmul_spmv_hybrid_nuq_perchannel_batched")
-            rc = fn(pr, pc, pvl, pv, pfr, pfi, pm, int(num_rows), pq, pl, height, width, nnz, topX, batch, K, stream)
-        else:
-            fn = getattr(lib, f"sqllm_vecquant{bits}matmul_spmv_hybrid_nuq_perchannel")
-            rc = fn(pr, pc, pvl, pv, pfr, pfi, pm, int(num_rows), pq, pl, height, width, nnz, topX, stream)
-    _lib.check(rc, fn.__name__)
+    _io_type(vec, mul)
+    pq, dev, height, width, K = _qweight(matq, bits, f"mat{bits}")
+    pl = _lut(lookup_table, width, bits, dev)
+    pr, pc, pvl, nnz = _csr(rows, cols, mat, num_rows, width, dev)
+    efr, efi = _persist(full_rows, _F32, "full_rows"), _persist(full_row_indices, _I32, "full_row_indices")
+    if len(efr[3]) != 2 or efr[3][0] != K:
+        raise ValueError(f"full_rows must be [{K}, topX], got {efr[3]}")
+    topX = efr[3][1]
+    n_idx = 1
+    for d in efi[3]:
+        n_idx *= d
+    if n_idx != topX:
+        raise ValueError(f"full_row_indices must have {topX} entries, got {n_idx}")
+    if efr[2] != dev or efi[2] != dev:
+        raise RuntimeError(f"all operands must be on cuda:{dev}, found full_rows / full_row_indices elsewhere")
+    pv, pm, batch = _vec_mul(vec, mul, K, width, batched, dev)
+    fn = _fn(f"sqllm_vecquant{bits}matmul_spmv_hybrid_nuq_perchannel{_SFX[batched]}")
+    head = (pr, pc, pvl, pv, efr[1], efi[1], pm, int(num_rows), pq, pl, height, width, nnz, topX)
+    _launch(fn, dev, head + (batch, K) if batched else head)
 
 
 def _balanced(bits, rows, cols, startrows, vals, vec, mul, matq, lookup_table, outfeatures, num_threads, numvals):
-    height, width, K, _ = _dense_shapes(vec, matq, mul, lookup_table, bits, False)
-    nnz = _csr_shapes(rows, cols, vals, outfeatures, width)
+    _io_type(vec, mul)
+    pq, dev, height, width, K = _qweight(matq, bits, f"mat{bits}")
+    pl = _lut(lookup_table, width, bits, dev)
+    pr, pc, pvl, nnz = _csr(rows, cols, vals, outfeatures, width, dev, "vals")
     if int(numvals) != nnz:
         raise ValueError(f"numvals ({numvals}) != number of stored values ({nnz})")
-    pr, pc, pvl = _dev_ptr(rows, _I32, "rows"), _dev_ptr(cols, _I32, "cols"), _dev_ptr(vals, _F32, "vals")
-    psr = _dev_ptr(startrows, _I32, "startrows") if startrows is not None else None
-    pv, pq = _dev_ptr(vec, _F32, "vec"), _dev_ptr(matq, _I32, f"mat{bits}")
-    pm, pl = _dev_ptr(mul, _F32, "mul"), _dev_ptr(lookup_table, _F32, "lookup_table")
-    _same_device(vec, rows, cols, vals, matq, mul, lookup_table)
-    lib = _lib.load()
-    fn = getattr(lib, f"sqllm_vecquant{bits}matmul_spmv_balanced_nuq_perchannel")
-    with _on_device_of(vec) as stream:
-        rc = fn(pr, pc, psr, pvl, pv, pm, pq, pl, int(outfeatures), int(num_threads), nnz, height, width, stream)
-    _lib.check(rc, fn.__name__)
+    psr = _persist(startrows, _I32, "startrows")[1] if startrows is not None else None
+    pv, pm, _ = _vec_mul(vec, mul, K, width, False, dev)
+    fn = _fn(f"sqllm_vecquant{bits}matmul_spmv_balanced_nuq_perchannel")
+    _launch(fn, dev, (pr, pc, psr, pvl, pv, pm, pq, pl, int(outfeatures), int(num_threads), nnz, height, width))
 
 
 # ---- the reference names (quant_cuda.cpp:257-270) ----------------------------------------------
