@@ -439,7 +439,7 @@ def drop_in_legs(layers, xs, dev, args, sync, model_layers, per_layer):
     on the first 8 decoder layers, scaled to the model."""
     import torch
 
-    from squeezellm_amd import decode, quant
+    from squeezellm_amd import _lib, decode, quant, synth
 
     rec = {}
     ys = [torch.zeros(l["N"], device=dev) for l in layers]
@@ -448,7 +448,49 @@ def drop_in_legs(layers, xs, dev, args, sync, model_layers, per_layer):
     blocks = time_blocks(g.replay, sync, 20, 3, 3)
     ms = statistics.median(blocks) / 20 * 1e3
     rec["op_per_linear_graph"] = {"launches_per_token": seq.n_groups, "ms_per_token": round(ms, 4), "tokens_per_s": round(1e3 / ms, 1)}
-    del seq, g, ys
+    del seq, g
+    # the same 224 operator calls EAGER through the Python names of quant_cuda (what unchanged quant.py issues, minus its
+    # three torch launches per linear): host-bound or kernel-bound, whichever is slower
+    from squeezellm_amd import quant_cuda as qc
+
+    fn = getattr(qc, CONFIGS["7b-w4-s0"]["op"])
+    calls = [(x, l["qweight"], y, l["lookup_table"]) for l, x, y in zip(layers, xs, ys)]
+
+    def eager_ops():
+        for c in calls:
+            fn(*c)
+
+    blocks = time_blocks(eager_ops, sync, 5, 2, 3)
+    ms = statistics.median(blocks) / 5 * 1e3
+    rec["op_per_linear_eager"] = {"launches_per_token": len(calls), "ms_per_token": round(ms, 4), "tokens_per_s": round(1e3 / ms, 1)}
+    # what one call costs on the host: the queue is never drained inside the loop, so wall / calls = host time per call
+    tiny = synth.make_layer(256, 256, 4, device=dev, seed=7)
+    tx, ty = torch.randn(256, device=dev), torch.zeros(256, device=dev)
+
+    def host_us(f, n=4000):
+        for _ in range(200):
+            f()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            f()
+        dt = time.perf_counter() - t0
+        sync()
+        return round(dt / n * 1e6, 2)
+
+    lib = _lib.load()
+    op = _lib.SqllmOp(bits=4, batch=0, K=256, N=256)
+    op.vec, op.qweight, op.mul, op.lookup_table = tx.data_ptr(), tiny["qweight"].data_ptr(), ty.data_ptr(), tiny["lookup_table"].data_ptr()
+    ref, stream = ctypes.byref(op), torch.cuda.current_stream(dev).cuda_stream
+    rec["host_cost_us"] = {
+        "quant_cuda_call": host_us(lambda: fn(tx, tiny["qweight"], ty, tiny["lookup_table"])),
+        "c_abi_launch_premarshalled": host_us(lambda: lib.sqllm_launch(ref, stream)),
+        "torch_zero_": host_us(lambda: ty.zero_()),
+        "torch_zeros": host_us(lambda: torch.zeros(256, device=dev)),
+        "note": "eager host microseconds per call on this box (256 x 256 layer: the kernel is shorter than the call); quant.py's forward adds "
+                "three torch launches (zeros / x.float() / y.to) to every operator call",
+    }
+    del ys, calls
     n_dec = min(8, model_layers)
     sub = layers[:n_dec * per_layer]
     scale = model_layers / n_dec
@@ -495,9 +537,27 @@ def drop_in_legs(layers, xs, dev, args, sync, model_layers, per_layer):
     for m in mods:
         m.__class__ = quant.QuantLinearLUTFused
     run(mods)  # (first call: CSR check, workspace)
+    t = timed(lambda: run(mods), 5)
+    rec["fused_linear_eager"] = {"launches_per_linear": 1, "ms_per_token": round(t, 4), "tokens_per_s": round(1e3 / t, 1)}
     gr = capture(lambda: run(mods))
     t = timed(gr.replay, 20)
     rec["fused_linear_graph"] = {"launches_per_linear": 1, "ms_per_token": round(t, 4), "tokens_per_s": round(1e3 / t, 1)}
+    # the fused linear's KERNEL against the operator's, like for like: both as pre-marshalled C-ABI sequences of one launch
+    # per linear (no module, no torch op in the graph), the same decoder layers
+    ys16 = [torch.empty(l["N"], device=dev, dtype=torch.float16) for l in sub]
+    x16f = [x.reshape(-1) for x in xs16]
+    lin_seq = decode.OpSequence(sub, x16f, ys16, fuse_shared_input=False, linear=True)
+    g2 = lin_seq.graph(warmup=1)
+    t_lin = timed(g2.replay, 20)
+    ys32 = [torch.zeros(l["N"], device=dev) for l in sub]
+    op_seq = decode.OpSequence(sub, xs[:len(sub)], ys32, fuse_shared_input=False)
+    g3 = op_seq.graph(warmup=1)
+    t_op = timed(g3.replay, 20)
+    rec["fused_linear_kernel_vs_operator"] = {"fused_linear_sequence_ms": round(t_lin, 4), "operator_sequence_ms": round(t_op, 4),
+                                              "overhead_pct": round((t_lin / t_op - 1) * 100, 1),
+                                              "note": "C-ABI sequences, one launch per linear each, graph replay; the gap between this and "
+                                                      "fused_linear_graph is the torch-captured module path, not the kernel"}
+    del g2, g3, lin_seq, op_seq, ys16, ys32
     rec["note"] = (f"forward_* and fused_linear_graph: {n_dec} of {model_layers} decoder layers timed, scaled; fp16 activations; "
                    "the headline `value` needs the grouped-launch entry point (sqllm_launch_groups / OpSequence), "
                    "which squeezellm/quant.py unchanged does not call")

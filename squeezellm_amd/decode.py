@@ -26,17 +26,22 @@ def _ptr(t):
 
 def fold_topx_into_csr(lay):
     """(rows, cols, vals) of a layer's CSR with its top-X dense rows folded back in as ordinary CSR rows (an entry
-    present in both is summed), on the layer's device; cached in the layer dict under "csr_with_topx".
+    present in both is summed), on the layer's device; cached in the layer dict under "csr_with_topx", keyed on the
+    buffers it was built from (pointers, sizes, in-place version counters).
 
     The reference keeps the few densest outlier rows as dense `full_rows` because its SpMV walks one row per
     thread (quant_cuda_kernel.cu:1049-1058); the CSR role here is balanced by non-zeros, so a heavy row costs
     nothing extra, and the FUSED LINEAR -- which has to fold the top-X rows into its dense tiles, its most
     expensive term -- is faster with them in the CSR.  The operator path keeps the reference's
     operands as they are."""
-    hit = lay.get("csr_with_topx")
-    if hit is not None:
-        return hit
     full_rows, full_idx = lay["full_rows"], lay["full_row_indices"]
+    # the cache entry is only good for the very buffers (and contents) it was built from: a column shard that was
+    # copied from this dict, or an in-place edit of the outlier values, must not see it
+    src = [full_rows, full_idx] + ([lay["rows"], lay["cols"], lay["vals"]] if lay.get("vals") is not None else [])
+    cache_key = (lay["N"],) + tuple((t.data_ptr(), t.numel(), t._version) for t in src)
+    hit = lay.get("csr_with_topx")
+    if hit is not None and hit[0] == cache_key:
+        return hit[1]
     dev = full_rows.device
     N, K = lay["N"], full_rows.shape[0]
     if lay.get("vals") is not None and lay["vals"].numel():
@@ -57,7 +62,7 @@ def fold_topx_into_csr(lay):
     new_rows = torch.zeros(N + 1, dtype=torch.int32, device=dev)
     new_rows[1:] = torch.bincount(uniq // K, minlength=N).cumsum(0).to(torch.int32)
     out = (new_rows, (uniq % K).to(torch.int32).contiguous(), v.contiguous())
-    lay["csr_with_topx"] = out
+    lay["csr_with_topx"] = (cache_key, out)
     return out
 
 

@@ -141,7 +141,7 @@ class QuantLinearLUTFused(QuantLinearLUT):
         must not share the accumulator words, hence the stream in the key."""
         cache = self.__dict__.setdefault("_ws", {})
         need = _lib.linear_workspace_bytes(self.outfeatures, batch)
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        key = (device, quant_cuda._raw_stream(device.index if device.index is not None else torch.cuda.current_device()))
         ws = cache.get(key)
         if ws is None or ws.numel() < need:
             ws = torch.zeros(need, dtype=torch.uint8, device=device)  # zero-filled once
@@ -153,7 +153,7 @@ class QuantLinearLUTFused(QuantLinearLUT):
         inconsistent CSR (rows not non-decreasing, rows[N] != nnz -- e.g. buffers not loaded yet)
         would leave columns unfinished and the shared workspace dirty for every later call.  Checked
         once per module and CSR buffer (one device round trip), so that it fails loudly instead."""
-        key = (self.rows.data_ptr(), self.vals.data_ptr(), self.vals.numel())
+        key = (self.rows.data_ptr(), self.rows._version, self.vals.data_ptr(), self.vals.numel())
         if self.__dict__.get("_csr_ok") == key:
             return
         if torch.cuda.is_current_stream_capturing():
@@ -168,12 +168,15 @@ class QuantLinearLUTFused(QuantLinearLUT):
     fold_topx = True  # fold the top-X dense rows into the CSR the fused kernel is given (set False to pass them separately)
 
     def _csr_with_topx(self):
-        """(rows, cols, vals) with the top-X rows folded in, built once per buffer set (decode.fold_topx_into_csr);
-        not built while the stream is capturing -- that call then passes the top-X rows separately."""
+        """(rows, cols, vals) with the top-X rows folded in (decode.fold_topx_into_csr), rebuilt whenever one of the
+        buffers it was built from is replaced OR written in place (load_state_dict copies into the same storage: the
+        key carries the tensors' version counters); not built while the stream is capturing -- that call then passes
+        the top-X rows separately."""
         from . import decode
 
         has_csr = self.numvals > 0
-        key = (self.full_rows.data_ptr(), self.full_row_indices.data_ptr(), self.vals.data_ptr() if has_csr else 0, self.numvals)
+        src = [self.full_rows, self.full_row_indices] + ([self.rows, self.cols, self.vals] if has_csr else [])
+        key = tuple((t.data_ptr(), t._version) for t in src) + (self.numvals,)
         hit = self.__dict__.get("_folded")
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -215,9 +218,7 @@ class QuantLinearLUTFused(QuantLinearLUT):
                 o.full_rows, o.full_row_indices, o.topX = self.full_rows.data_ptr(), self.full_row_indices.data_ptr(), self.topX
         lin.bias = None if self.bias is None else self.bias.data_ptr()
         lin.workspace = self._workspace(batch, x.device).data_ptr()
-        with quant_cuda._on_device_of(x) as stream:
-            rc = _lib.load().sqllm_linear_f16(ctypes.byref(lin), stream)
-        _lib.check(rc, "sqllm_linear_f16")
+        quant_cuda._launch(quant_cuda._fn("sqllm_linear_f16"), x.get_device(), (ctypes.byref(lin),))
         return out.reshape(*x.shape[:-1], N)
 
 

@@ -66,10 +66,10 @@ def _dev_ptr(t, dtype, name: str) -> int:
         raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
     if t.dtype != dtype:
         raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
-    if not t.is_cuda:
-        raise RuntimeError(f"{name} must be a GPU tensor (quant_cuda has no CPU path), got device {t.device}")
     if not t.is_contiguous():
         raise ValueError(f"{name} must be contiguous")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor (quant_cuda has no CPU path), got device {t.device}")
     return t.data_ptr()
 
 

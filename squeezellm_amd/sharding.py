@@ -145,6 +145,7 @@ def shard_layer_columns(layer: dict, rank: int, world_size: int, align: int = 64
     on CPU and GPU tensors alike; the result is a valid operand set for every operator of the library."""
     n0, n1 = column_ranges(layer["N"], world_size, align)[rank]
     out = dict(layer)
+    out.pop("csr_with_topx", None)  # (a derived entry of the unsharded layer: decode.fold_topx_into_csr rebuilds it for the shard)
     out["N"] = n1 - n0
     out["col_range"] = (n0, n1)
     out["qweight"] = layer["qweight"][:, n0:n1].contiguous()

@@ -41,3 +41,22 @@ def test_folded_csr_is_the_same_matrix():
         for r in range(N):
             seg = c2[int(r2[r]):int(r2[r + 1])].numpy()
             assert (np.diff(seg) > 0).all()
+
+
+def test_fold_cache_is_keyed_on_the_buffers_it_was_built_from():
+    """the folded CSR cached in the layer dict must not leak into a column shard copied from that dict, and
+    must be rebuilt after an in-place edit of the operands."""
+    import torch
+
+    from squeezellm_amd import decode, sharding, synth
+
+    lay = synth.make_layer(256, 256, 4, sparse_frac=0.02, topX=4, heavy_rows=2, device="cpu", seed=3)
+    full = decode.fold_topx_into_csr(lay)
+    assert full[0].numel() == 257
+    shard = sharding.shard_layer_columns(lay, 1, 2)
+    sh = decode.fold_topx_into_csr(shard)
+    assert sh is not full and sh[0].numel() == shard["N"] + 1 and int(sh[0][-1]) == sh[2].numel()
+    assert decode.fold_topx_into_csr(lay) is full  # unchanged operands: the cached result
+    lay["vals"].mul_(2.0)  # in-place edit
+    again = decode.fold_topx_into_csr(lay)
+    assert again is not full and not torch.equal(again[2], full[2])

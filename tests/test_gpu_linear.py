@@ -327,3 +327,27 @@ def test_fused_module_with_and_without_folded_topx(gpu, bits, rows):
             assert ("_folded" in mod.__dict__) == fold
             _check_fp16(y.cpu().numpy(), exact)
             outs.append(y)
+
+
+def test_fused_linear_sees_operands_refreshed_in_place(gpu):
+    """a module that ran one forward and then had its outlier buffers refreshed IN PLACE (what
+    load_state_dict does: same storage, new contents) must not keep computing with the folded CSR it built from the
+    old contents."""
+    import torch
+
+    from squeezellm_amd import quant, synth
+
+    lay = synth.make_layer(512, 256, 4, sparse_frac=0.01, topX=6, heavy_rows=2, device=gpu, seed=77)
+    mod = quant.QuantLinearLUT.from_operands(lay)
+    mod.__class__ = quant.QuantLinearLUTFused
+    x = torch.randn(1, 512, device=gpu, dtype=torch.float16)
+    y0 = mod(x).float()
+    with torch.no_grad():
+        mod.vals.mul_(-3.0)       # in place: same pointers
+        mod.full_rows.mul_(0.0)
+    y1 = mod(x).float()
+    ref = quant.QuantLinearLUT.from_operands(lay)  # the reference-style forward reads the live buffers
+    want = ref(x).float()
+    torch.cuda.synchronize()
+    assert not torch.allclose(y0, y1, atol=1e-3)
+    assert torch.allclose(y1, want, atol=2e-3 * float(want.abs().max())), float((y1 - want).abs().max())
