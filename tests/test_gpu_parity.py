@@ -300,3 +300,60 @@ def test_csr_row_segment_structures(qc, gpu, bits):
         for batch in (0, 3, 8, 16, 40):  # fused kernel (1 / 4 / 8-row tiles), then the wide-batch sparse launch (lane groups / scalar walk)
             x, mul, got = run_op(qc, gpu, case, "spmv", batch)
             assert H.rel_err(got, H.oracle_ref(case, x, mul, "spmv")) <= TOL_FP64, (name, batch)
+
+
+@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 11008), (11008, 4096)], ids=["4096x4096", "4096x11008", "11008x4096"])
+@pytest.mark.parametrize("bits", [3, 4])
+def test_all_reference_launchers_at_baseline_shapes(gpu, bits, K, N):
+    """The three LLaMA-7B shapes of BASELINE configs[1] / [2] through ALL TWELVE reference launchers
+    (squeezellm/quant_cuda_kernel.cu:132-738: dense / spmv / hybrid x matvec / batched x 3 / 4 bit; the shapes satisfy the
+    reference's % 128 limits, :754, :841), compiled unmodified into oracle/_ref: the reference's kernels, ours and the C
+    oracle on the same operands.  Pins the oracle to the reference at full size (the golden vectors are K = 256, N = 128),
+    and is the correctness half of the same-box timing in profiles/r04_ref_vs_ours_*.json."""
+    import ctypes
+    import os
+
+    import torch
+
+    from squeezellm_amd import quant_cuda as qcm
+
+    path = os.path.join(H.ROOT, "oracle", "_ref", "libsqllm_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libsqllm_ref.so not built (needs /root/reference at build time)")
+    ref = ctypes.CDLL(path)
+    ref.refk_set_sync(1)
+    P = ctypes.c_void_p
+    lib = H.c_oracle()
+    case = H.make_case(bits, K, N, sparse=0.0045, topX=10, heavy_rows=10, seed=1000 + bits + K % 97)
+    t = H.to_torch(case, gpu)
+    rng = np.random.default_rng(17)
+    for batch in (0, 3):
+        x = torch.from_numpy(rng.normal(size=(batch, K) if batch else (K,)).astype(np.float32)).to(gpu)
+        mul0 = torch.from_numpy((rng.normal(size=(batch, N) if batch else (N,)) * 0.01).astype(np.float32)).to(gpu)
+        for kind in ("dense", "spmv", "hybrid"):
+            ours, theirs = mul0.clone(), mul0.clone()
+            H.call_op(qcm, t, x, ours, kind, batch > 0)
+            if kind == "dense":
+                rc = ref.refk_dense(bits, batch, P(x.data_ptr()), P(t["qweight"].data_ptr()), P(theirs.data_ptr()),
+                                    P(t["lookup_table"].data_ptr()), K, N)
+            elif kind == "spmv":
+                rc = ref.refk_spmv(bits, batch, P(t["rows"].data_ptr()), P(t["cols"].data_ptr()), P(t["vals"].data_ptr()),
+                                   case["vals"].size, P(x.data_ptr()), P(theirs.data_ptr()), N, P(t["qweight"].data_ptr()),
+                                   P(t["lookup_table"].data_ptr()), K, N)
+            else:
+                rc = ref.refk_hybrid(bits, batch, P(t["rows"].data_ptr()), P(t["cols"].data_ptr()), P(t["vals"].data_ptr()),
+                                     case["vals"].size, P(x.data_ptr()), P(t["full_rows"].data_ptr()),
+                                     P(t["full_row_indices"].data_ptr()), 10, P(theirs.data_ptr()), N,
+                                     P(t["qweight"].data_ptr()), P(t["lookup_table"].data_ptr()), K, N)
+            assert rc == 0, (kind, batch, rc)
+            torch.cuda.synchronize()
+            sub = dict(case)
+            if kind == "dense":
+                sub.update(rows=None, cols=None, vals=None)
+            if kind != "hybrid":
+                sub.update(full_rows=None, full_row_indices=None)
+            want = H.c_matvec(lib, sub, x.cpu().numpy(), mul0.cpu().numpy(), batched=batch > 0)
+            what = f"w{bits} {K}x{N} {kind} batch {batch}"
+            assert H.rel_err(theirs.cpu().numpy(), want) <= TOL_FP64, f"{what}: reference kernels vs oracle"
+            assert H.rel_err(ours.cpu().numpy(), want) <= TOL_FP64, f"{what}: ours vs oracle"
+            assert H.rel_err(ours.cpu().numpy(), theirs.cpu().numpy()) <= TOL_FP64, f"{what}: ours vs reference kernels"
