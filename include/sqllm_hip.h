@@ -276,6 +276,10 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     a captured wide-batch op with a CSR term then carries a memory-allocation
  *                     and a memory-free node in the graph; 0 keeps captures allocation-free (the
  *                     CSR term gathers from vec instead)
+ *   "mfma_split"      1 (default): the dense term of a wide batch (mfma_min_batch rows and more) runs on the bf16 matrix
+ *                     instructions with every fp32 operand split EXACTLY into three bf16 values and six of the nine partial
+ *                     products kept (fp32-class results, 2.7 x the matrix rate of the fp32 instruction); 0: the fp32 matrix
+ *                     instruction (bit-for-bit an fp32 FMA chain per output)
  *   "validate_csr"    debugging aid, default 0.  1 = before every launch that carries a CSR term,
  *                     check ON THE DEVICE that rows[] is non-decreasing with rows[0] == 0 and
  *                     rows[N] == nnz, and return SQLLM_E_SPARSE otherwise.  Blocks the host (one

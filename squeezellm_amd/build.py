@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_NAME = "libsqllm_hip.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
-SOURCES = ["sqllm_kernels.hip", "sqllm_capi.hip"]
+SOURCES = ["sqllm_kernels.hip", "sqllm_mfma_split.hip", "sqllm_capi.hip"]
 # measured-and-not-adopted kernels (round 3: the streaming batch-1 kernel, the column-pair-table kernel; round 4: the
 # dependency-gated persistent pass) and the host code that routes to them: csrc/experimental/, part of the MEASUREMENT
 # library only (options "stream" / "pair4", entry points sqllm_pass_*)

@@ -324,6 +324,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "sparse_transpose")) { knobs().sparse_transpose.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "scratch_in_capture")) { knobs().scratch_in_capture.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { knobs().validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
+  if (!strcmp(name, "mfma_split")) { knobs().mfma_split.store(value ? 1 : 0); return SQLLM_OK; }
   if (g_experimental.set_option) return g_experimental.set_option(name, value);  // (measurement library)
   return SQLLM_E_OPTION;
 }
@@ -341,6 +342,7 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "sparse_transpose")) { *value = knobs().sparse_transpose.load(); return SQLLM_OK; }
   if (!strcmp(name, "scratch_in_capture")) { *value = knobs().scratch_in_capture.load(); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { *value = knobs().validate_csr.load(); return SQLLM_OK; }
+  if (!strcmp(name, "mfma_split")) { *value = knobs().mfma_split.load(); return SQLLM_OK; }
   if (g_experimental.get_option) return g_experimental.get_option(name, value);  // (measurement library)
   return SQLLM_E_OPTION;
 }
@@ -501,7 +503,9 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
           if (rc != SQLLM_OK) return rc;
           a.ev_start = nullptr;
         }
-        rc = static_cast<int>(sqllm::launch_batched_mfma(op->bits, a, static_cast<hipStream_t>(stream)));
+        rc = static_cast<int>(knobs().mfma_split.load(std::memory_order_relaxed)
+                                  ? sqllm::launch_batched_mfma_split(op->bits, a, static_cast<hipStream_t>(stream))
+                                  : sqllm::launch_batched_mfma(op->bits, a, static_cast<hipStream_t>(stream)));
       } else {
         rc = static_cast<int>(sqllm::launch_batched_cols(op->bits, a, static_cast<hipStream_t>(stream)));
       }

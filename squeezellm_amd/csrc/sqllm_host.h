@@ -30,6 +30,7 @@ struct Knobs {
   std::atomic<int> scratch_in_capture{1};  // stream-ordered scratch also while the stream is capturing (graph memory nodes)
   std::atomic<int> sparse_transpose{1};  // wide batches: the CSR role reads a transposed copy of vec (stream-ordered scratch)
   std::atomic<int> validate_csr{0};    // debug: check rows[] on the device before every launch that carries a CSR term
+  std::atomic<int> mfma_split{1};      // wide batches: bf16 matrix instructions on exactly split operands (0: the fp32 matrix instruction)
 };
 constexpr int kMaxDevices = 32;
 

@@ -147,7 +147,8 @@ hipError_t launch_pair4(const LaunchArgs& a, hipStream_t stream);  // 4-bit, bat
 // `ga`: the sparse roles of the launch (block0[] = prefix over csr + top-X workgroups only)
 hipError_t launch_stream(int bits, const StreamArgs& sa, const GroupArgs& ga, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
                          int ablate);
-hipError_t launch_batched_mfma(int bits, const LaunchArgs& a, hipStream_t stream);
+hipError_t launch_batched_mfma(int bits, const LaunchArgs& a, hipStream_t stream);        // fp32 matrix instructions
+hipError_t launch_batched_mfma_split(int bits, const LaunchArgs& a, hipStream_t stream);  // bf16 matrix instructions on exactly split operands (sqllm_mfma_split.hip)
 hipError_t launch_batched_cols(int bits, const LaunchArgs& a, hipStream_t stream);
 hipError_t transpose_vec(const float* x, float* xT, int batch, int K, int Bp, hipStream_t stream, hipEvent_t ev_start);
 hipError_t launch_batched_sparse(const LaunchArgs& a, hipStream_t stream);

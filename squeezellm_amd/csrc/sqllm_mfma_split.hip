@@ -1,0 +1,383 @@
+// sqllm_mfma_split.hip -- wide-batch dense term on the bf16 MATRIX cores with fp32-class results: the *_batched
+// operators from `mfma_min_batch` rows up (reference: one weight pass PER BATCH ROW, squeezellm/quant_cuda_kernel.cu:
+// 884-979 / :982-1038).
+//
+// The fp32 matrix instruction (v_mfma_f32_16x16x4_f32, sqllm_kernels.hip: dense_role_mfma) runs at the fp32 VECTOR
+// rate -- 1/16 of the bf16 matrix rate (MI355X_MICROARCH.md: 155 vs 2075-2382 TFLOP/s measured) -- so a wide batch was
+// bound by the matrix pipe: 13B gate/up 30 us for 9..16 rows, 2048 rows 2.4 ms (120 of 157 TFLOP/s).  Here every fp32
+// operand is written as the EXACT sum of three bf16 values,
+//         v = hi + mid + lo,   hi = top 8 significant bits of v, mid = the next 8, lo = the last 8
+// (truncations of v, v - hi, v - hi - mid: each difference is exact in fp32), and the product w * x as the six
+// partial products whose magnitude can reach 2^-16 of it or more:
+//         w x  ~  wh xh + wh xm + wm xh + wh xl + wl xh + wm xm            (dropped: wm xl, wl xm, wl xl <= 2^-24 |w x|)
+// A bf16 x bf16 product is exact in fp32, the matrix instruction accumulates in fp32, so the result carries the
+// rounding of an fp32 FMA chain plus 3 x 2^-24 per product: fp32 class (measured against the fp64 oracle next to the
+// fp32 kernel: tests/test_gpu_batched.py, same 2e-5 gate, observed ~3e-7).  Six v_mfma_f32_16x16x32_bf16 (32 k's
+// each, 16 cycles) replace 8 x v_mfma_f32_16x16x4_f32 (4 k's each, 32 cycles): 96 instead of 256 matrix-pipe cycles
+// per 16 rows x 16 columns x 32 k's.
+//
+// Where the splits come from:
+//   * weights: the tile's codebook is staged in LDS ALREADY SPLIT -- an 8-byte entry {hi | mid << 16, lo} per
+//     (column, index), layout [column j of the lane's four][index][32 slots x 8 B] (two copies of the 16 column
+//     groups side by side: a half-wave's ds_read_b64 then touches 32 different 8-byte slots of one 256-byte row,
+//     conflict-free whatever the indices are); a lookup is ONE ds_read_b64 per weight, addressed by one
+//     v_perm_b32 as in the batch-1 kernel, and three v_perm_b32 per TWO weights pack the halves into the operand
+//     registers;
+//   * vec: lane (c, kq) of the wave reads the 8 consecutive k's of batch row c that belong to ITS qweight row
+//     straight from global memory (32 bytes; the four lane rows cover one 128-byte line per batch row) and splits
+//     them in registers: and / sub / and / sub per value + the same packing.
+// Operand mapping: lane (c = l % 16, kq = l / 16) holds nibbles 0..7 of its own packed word = k = 8 (r0 + kq) + s as
+// the 8 elements of its B fragment, and x[row c][8 (r0 + kq) + s] as its A fragment: both sides enumerate the k's
+// of a matrix instruction the same way, which is all it needs (no cross-lane traffic; cf. dense_role_mfma).
+// Work decomposition, prefetch ping-pong, LDS meeting of the waves and the epilogue are the fp32 kernel's.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "sqllm_kernels.h"
+
+#include "sqllm_decode.h"
+
+namespace sqllm {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int split_codebook_bytes(int bits) { return 4 * (1 << bits) * 256; }  // [4 columns][index][32 slots x 8 B]
+constexpr int split_lds_floats(int bits, int waves) {
+  // codebooks, then the epilogue's slabs [waves][16][64]
+  return split_codebook_bytes(bits) / 4 + waves * 16 * 64;
+}
+
+__device__ __forceinline__ u32x2 lds_read_u32x2(uint32_t byte_addr) {
+  return *reinterpret_cast<const u32x2 __attribute__((address_space(3)))*>(byte_addr);
+}
+
+// 3-bit field KIDX of a unit's 96-bit stream, shifted to bit 8 (an entry row is 256 bytes here)
+template <int KIDX>
+__device__ __forceinline__ uint32_t field3_x256(uint32_t t0, uint32_t t1, uint32_t t2) {
+  constexpr int bit = 3 * KIDX;
+  constexpr int w = bit >> 5;
+  constexpr int o = bit & 31;
+  const uint32_t lo = (w == 0) ? t0 : (w == 1) ? t1 : t2;
+  uint32_t f;
+  if constexpr (o <= 29) {
+    if constexpr (o > 8) f = lo >> (o - 8);
+    else if constexpr (o < 8) f = lo << (8 - o);
+    else f = lo;
+  } else {
+    const uint32_t hi = (w == 0) ? t1 : t2;
+    f = __builtin_amdgcn_alignbit(hi, lo, o) << 8;
+  }
+  return f & 0x700u;
+}
+
+// exact three-way split of eight fp32 values into packed bf16 operand registers
+__device__ __forceinline__ void split8(const float (&v)[8], uint32_t (&h)[4], uint32_t (&m)[4], uint32_t (&l)[4]) {
+  uint32_t hb[8], mb[8], lb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, v[i]);
+    hb[i] = b & 0xFFFF0000u;
+    const float r1 = v[i] - __builtin_bit_cast(float, hb[i]);  // exact
+    mb[i] = __builtin_bit_cast(uint32_t, r1) & 0xFFFF0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, mb[i]);    // exact, <= 8 significant bits
+    lb[i] = __builtin_bit_cast(uint32_t, r2);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // element 2i in the low half, 2i + 1 in the high half
+    h[i] = __builtin_amdgcn_perm(hb[2 * i + 1], hb[2 * i], 0x07060302u);
+    m[i] = __builtin_amdgcn_perm(mb[2 * i + 1], mb[2 * i], 0x07060302u);
+    l[i] = __builtin_amdgcn_perm(lb[2 * i + 1], lb[2 * i], 0x07060302u);
+  }
+}
+
+__device__ __forceinline__ bf16x8 as_frag(const uint32_t (&r)[4]) {
+  typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(bf16x8, u32x4v{r[0], r[1], r[2], r[3]});
+}
+
+template <int BITS, int MB, int WAVES>
+__device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ x, const u32x4* __restrict__ q,
+                                                      float* __restrict__ y, const float* __restrict__ lut, int K, int N,
+                                                      int batch, int m0, int bid, int n_col_tiles, int units_total,
+                                                      int units_per_wg, int units_stride, float* lds) {
+  using F = Fmt<BITS>;
+  constexpr int L = F::kLut, R = F::kRows, KU = F::kK;
+  constexpr int NPH = KU / 8;  // phases of 8 k's per unit (4-bit: 1, 3-bit: 4)
+  constexpr int T = WAVES * 64;
+  __builtin_amdgcn_s_waitcnt(0);  // clean slate for the compiler's wait-count model (see dense_role)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, grp = lane >> 4;
+  constexpr int kCbBytes = split_codebook_bytes(BITS);
+  float* slabs = lds + kCbBytes / 4;
+  const int row_stride = N / 4;  // in 16-byte units
+  const char* qbase = reinterpret_cast<const char*>(q);
+  const uint32_t row_bytes = 16u * (uint32_t)row_stride;
+  // this lane's batch rows: row i16 of every block of 16 (rows past the batch re-read its last row; never stored)
+  int xrow[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    int r = m0 + 16 * mb + i16;
+    if (r > batch - 1) r = batch - 1;
+    xrow[mb] = r * K;
+  }
+  const uint32_t lane_off = 8 * (i16 + 16 * (grp & 1));  // byte offset of this lane's slot inside an entry row
+
+  const unsigned total = (unsigned)n_col_tiles * (unsigned)units_stride;
+  unsigned gpos = (unsigned)bid * (unsigned)units_per_wg;
+  unsigned gend = gpos + (unsigned)units_per_wg;
+  if (gend > total) gend = total;
+  while (gpos < gend) {
+  const int ct = (int)(gpos / (unsigned)units_stride);
+  const int u_beg = (int)(gpos - (unsigned)ct * (unsigned)units_stride);
+  if (u_beg >= units_total) { gpos = (unsigned)(ct + 1) * (unsigned)units_stride; continue; }  // (padding behind a tile's last range)
+  int u_end = units_total;
+  if ((unsigned)(u_end - u_beg) > gend - gpos) u_end = u_beg + (int)(gend - gpos);
+  gpos += (unsigned)(u_end - u_beg);
+  if (u_end == units_total) gpos = (unsigned)(ct + 1) * (unsigned)units_stride;  // skip the padding
+  const int col0 = ct * kTileN;
+
+  // ---- codebook values this thread stages: entry e = tid + T i of the tile's 4 * L * 32 eight-byte entries;
+  //      row = e / 32 = (column j, index), slot = e % 32 = (copy, column group) ----
+  constexpr int NST = 4 * L * 32 / T;
+  float ev[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int e = tid + T * i;
+    const int row = e >> 5, slot = e & 31;
+    int c = col0 + 4 * (slot & 15) + row / L;
+    if (c > N - 1) c = N - 1;
+    ev[i] = lut[(size_t)c * L + (row % L)];
+  }
+  const int n_groups_wg = (u_end - u_beg + 3) / 4;
+  const int n_g = n_groups_wg > wave ? (n_groups_wg - wave + WAVES - 1) / WAVES : 0;
+  int cidx = col0 / 4 + i16;
+  if (cidx > row_stride - 1) cidx = row_stride - 1;
+  const uint32_t lane_bytes = 16u * (uint32_t)cidx;
+  auto group_unit = [&](int g) {  // unit of this lane's row in the wave's group g (may be >= u_end)
+    return u_beg + 4 * (wave + WAVES * g) + grp;
+  };
+  auto clamp_unit = [&](int u) {
+    if (u > u_end - 1) u = u_end - 1;  // clamped re-read inside the slice; its x values are zeroed
+    if (u < u_beg) u = u_beg;
+    return u;
+  };
+  auto load_w = [&](int g, u32x4 (&dw)[R]) {
+    const int u = clamp_unit(group_unit(g));
+    const uint32_t off = (uint32_t)(u * R) * row_bytes + lane_bytes;
+#pragma unroll
+    for (int r = 0; r < R; ++r) dw[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(qbase + (off + r * row_bytes)));
+  };
+  auto load_x = [&](int g, int ph, f32x4 (&dx)[2 * MB]) {
+    const int u = clamp_unit(group_unit(g));
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const float* p = x + xrow[mb] + u * KU + 8 * ph;
+      dx[2 * mb] = *reinterpret_cast<const f32x4*>(p);
+      dx[2 * mb + 1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+  };
+  u32x4 wa[R], wb[R];
+  f32x4 xa[2 * MB], xb[2 * MB];
+  load_w(0, wa);
+  load_x(0, 0, xa);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- stage the codebooks, split ----
+  {
+    char* base = reinterpret_cast<char*>(lds);
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const uint32_t b = __builtin_bit_cast(uint32_t, ev[i]);
+      const uint32_t hb = b & 0xFFFF0000u;
+      const float r1 = ev[i] - __builtin_bit_cast(float, hb);
+      const uint32_t mbits = __builtin_bit_cast(uint32_t, r1) & 0xFFFF0000u;
+      const float r2 = r1 - __builtin_bit_cast(float, mbits);
+      *reinterpret_cast<u32x2*>(base + 8 * (tid + T * i)) = u32x2{(hb >> 16) | mbits, __builtin_bit_cast(uint32_t, r2) >> 16};
+    }
+  }
+  f32x4 acc[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();  // codebooks staged (and everybody has left the previous piece's slabs)
+
+  // one phase: the 8 k's of each lane row (phase PH of its unit) against all MB row blocks
+  auto phase = [&](const u32x4 (&t)[R], auto ph_tag, const f32x4 (&dx)[2 * MB], int g) {
+    constexpr int PH = decltype(ph_tag)::value;
+    const bool live = group_unit(g) < u_end;
+    // A fragments of every row block
+    uint32_t ah[MB][4], am[MB][4], al[MB][4];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const f32x4 lo4 = dx[2 * mb], hi4 = dx[2 * mb + 1];
+      float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = live ? v[i] : 0.f;
+      split8(v, ah[mb], am[mb], al[mb]);
+    }
+    uint32_t t0[4], t1[4], t2[4];
+    if constexpr (BITS == 4) {
+      t0[0] = t[0].x; t0[1] = t[0].y; t0[2] = t[0].z; t0[3] = t[0].w;
+    } else {
+      t0[0] = t[0].x; t0[1] = t[0].y; t0[2] = t[0].z; t0[3] = t[0].w;
+      t1[0] = t[1].x; t1[1] = t[1].y; t1[2] = t[1].z; t1[3] = t[1].w;
+      t2[0] = t[2].x; t2[1] = t[2].y; t2[2] = t[2].z; t2[3] = t[2].w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // the 8 weights of column 4c + j: one ds_read_b64 each
+      u32x2 e[8];
+      if constexpr (BITS == 4) {
+        const uint32_t lo = t0[j] & 0x0F0F0F0Fu, hi = (t0[j] >> 4) & 0x0F0F0F0Fu;
+        const int off = j * 4096;
+        e[0] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0400u) + off);
+        e[1] = lds_read_u32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0400u) + off);
+        e[2] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0500u) + off);
+        e[3] = lds_read_u32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0500u) + off);
+        e[4] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0600u) + off);
+        e[5] = lds_read_u32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0600u) + off);
+        e[6] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0700u) + off);
+        e[7] = lds_read_u32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0700u) + off);
+      } else {
+        const uint32_t tbj = j * 2048 + lane_off;
+        e[0] = lds_read_u32x2(tbj | field3_x256<8 * PH + 0>(t0[j], t1[j], t2[j]));
+        e[1] = lds_read_u32x2(tbj | field3_x256<8 * PH + 1>(t0[j], t1[j], t2[j]));
+        e[2] = lds_read_u32x2(tbj | field3_x256<8 * PH + 2>(t0[j], t1[j], t2[j]));
+        e[3] = lds_read_u32x2(tbj | field3_x256<8 * PH + 3>(t0[j], t1[j], t2[j]));
+        e[4] = lds_read_u32x2(tbj | field3_x256<8 * PH + 4>(t0[j], t1[j], t2[j]));
+        e[5] = lds_read_u32x2(tbj | field3_x256<8 * PH + 5>(t0[j], t1[j], t2[j]));
+        e[6] = lds_read_u32x2(tbj | field3_x256<8 * PH + 6>(t0[j], t1[j], t2[j]));
+        e[7] = lds_read_u32x2(tbj | field3_x256<8 * PH + 7>(t0[j], t1[j], t2[j]));
+      }
+      uint32_t bh[4], bm[4], bl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bh[i] = __builtin_amdgcn_perm(e[2 * i + 1].x, e[2 * i].x, 0x05040100u);  // the low halves: hi parts
+        bm[i] = __builtin_amdgcn_perm(e[2 * i + 1].x, e[2 * i].x, 0x07060302u);  // the high halves: mid parts
+        bl[i] = __builtin_amdgcn_perm(e[2 * i + 1].y, e[2 * i].y, 0x05040100u);
+      }
+      const bf16x8 Bh = as_frag(bh), Bm = as_frag(bm), Bl = as_frag(bl);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const bf16x8 Ah = as_frag(ah[mb]), Am = as_frag(am[mb]), Al = as_frag(al[mb]);
+        f32x4 c = acc[mb][j];
+        // small partial products first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, c, 0, 0, 0);
+        acc[mb][j] = c;
+      }
+    }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  using P3 = std::integral_constant<int, 3>;
+  // decode group g out of (w, xcur = its phase-0 vec values); later phases' values are loaded one phase ahead,
+  // the NEXT group's weights and phase-0 values (into wn / xn) before the first phase
+  auto decode_group = [&](int g, const u32x4 (&w)[R], f32x4 (&xcur)[2 * MB], u32x4 (&wn)[R], f32x4 (&xn)[2 * MB]) {
+    load_w(g + 1, wn);
+    if constexpr (NPH == 1) {
+      load_x(g + 1, 0, xn);
+      __builtin_amdgcn_sched_barrier(0);
+      phase(w, P0{}, xcur, g);
+    } else {
+      f32x4 xo[2 * MB];
+      load_x(g, 1, xo);
+      __builtin_amdgcn_sched_barrier(0);
+      phase(w, P0{}, xcur, g);
+      load_x(g, 2, xcur);
+      __builtin_amdgcn_sched_barrier(0);
+      phase(w, P1{}, xo, g);
+      load_x(g, 3, xo);
+      __builtin_amdgcn_sched_barrier(0);
+      phase(w, P2{}, xcur, g);
+      load_x(g + 1, 0, xn);
+      __builtin_amdgcn_sched_barrier(0);
+      phase(w, P3{}, xo, g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int g = 0; g < n_g; g += 2) {
+    decode_group(g, wa, xa, wb, xb);
+    decode_group(g + 1, wb, xb, wa, xa);
+  }
+
+  // ---- waves meet in LDS, one row block at a time (see dense_role_mfma) ----
+  float* slab = slabs + wave * (16 * 64) + (4 * grp) * 64 + 4 * i16;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    if (mb) __syncthreads();
+    *reinterpret_cast<f32x4*>(slab + 0 * 64) = f32x4{acc[mb][0].x, acc[mb][1].x, acc[mb][2].x, acc[mb][3].x};
+    *reinterpret_cast<f32x4*>(slab + 1 * 64) = f32x4{acc[mb][0].y, acc[mb][1].y, acc[mb][2].y, acc[mb][3].y};
+    *reinterpret_cast<f32x4*>(slab + 2 * 64) = f32x4{acc[mb][0].z, acc[mb][1].z, acc[mb][2].z, acc[mb][3].z};
+    *reinterpret_cast<f32x4*>(slab + 3 * 64) = f32x4{acc[mb][0].w, acc[mb][1].w, acc[mb][2].w, acc[mb][3].w};
+    __syncthreads();
+#pragma unroll
+    for (int e = tid; e < 16 * 64; e += WAVES * 64) {
+      const int r = m0 + 16 * mb + (e >> 6);
+      const int col = col0 + (e & 63);
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) sum += slabs[w * (16 * 64) + e];
+      if (r < batch && col < N) acc_add(y + (size_t)r * N + col, sum);
+    }
+  }
+  }  // pieces
+}
+
+template <int BITS, int MB, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, (MB == 1 || (BITS == 4 && MB == 2)) ? 4 : 2)
+sqllm_fused_batched_split(const float* x, const GroupArgs ga) {
+  __shared__ __attribute__((aligned(16))) float lds[split_lds_floats(BITS, WAVES)];
+  const Segment sg = ga.seg[0];  // the whole descriptor in one round of scalar loads (see sqllm_fused_matvec)
+  asm volatile("" ::SQLLM_SEG_OPERANDS(sg), "s"(x));
+  __builtin_amdgcn_sched_barrier(0);
+  const KernelGeom& gm = sg.gm;
+  const int m0 = blockIdx.y * 16 * MB;
+  dense_role_mfma_split<BITS, MB, WAVES>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, gm.batch, m0,
+                                         (int)blockIdx.x, gm.col_tiles, gm.units_total, gm.units_per_wg,
+                                         gm.dense_blocks == gm.col_tiles * gm.k_slices ? gm.k_slices * gm.units_per_wg : gm.units_total,
+                                         lds);
+}
+
+template <int BITS, int MB>
+hipError_t launch_split_inst(const LaunchArgs& a, hipStream_t stream) {
+  const KernelGeom& gm = a.ga.seg[0].gm;
+  dim3 grid(gm.dense_blocks, (gm.batch + 16 * MB - 1) / (16 * MB));
+  auto kern = sqllm_fused_batched_split<BITS, MB, kWaves>;
+  const float* x = static_cast<const float*>(a.x);
+  if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga);
+  else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga);
+  return hipGetLastError();
+}
+
+template <int BITS>
+hipError_t launch_split_bits(const LaunchArgs& a, hipStream_t stream) {
+  switch (mfma_row_blocks(a.ga.seg[0].gm.batch)) {
+    case 1: return launch_split_inst<BITS, 1>(a, stream);
+    case 2: return launch_split_inst<BITS, 2>(a, stream);
+    default: return launch_split_inst<BITS, 4>(a, stream);
+  }
+}
+
+}  // namespace
+
+// one op (a.ga.seg[0]), operator ABI, batch rows through the bf16 matrix cores with split operands (dense term only)
+hipError_t launch_batched_mfma_split(int bits, const LaunchArgs& a, hipStream_t stream) {
+  return bits == 4 ? launch_split_bits<4>(a, stream) : launch_split_bits<3>(a, stream);
+}
+
+}  // namespace sqllm
