@@ -258,7 +258,7 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     rows run on the column-lane kernel (lane = output column, vec in SGPRs),
  *                     mfma_min_batch rows and more on the fp32 matrix cores, everything else on the
  *                     batch tiles of the batch-1 kernel.  Defaults (value 0 = measured default, which
- *                     depends on the bit width; get_option returns the stored 0): 4-bit 2..4 / 9, 3-bit 2..16 / 17.
+ *                     depends on the bit width; get_option returns the stored 0): 4-bit 2..4 / 9, 3-bit 2..8 / 9.
  *                     With the two cols_* options at their defaults the column-lane kernel is further reserved
  *                     for what it measured faster on: 4-bit, groups of three or more ops and single ops of
  *                     >= 20 MB packed weights; 3-bit, >= 16 MB at up to 4 rows or N >= 8192; setting either option
@@ -280,6 +280,9 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     instructions with every fp32 operand split EXACTLY into three bf16 values and six of the nine partial
  *                     products kept (fp32-class results, 2.7 x the matrix rate of the fp32 instruction); 0: the fp32 matrix
  *                     instruction (bit-for-bit an fp32 FMA chain per output)
+ *   "mfma_fuse_small" 1 (default, with mfma_split): from mfma_min_batch up to 16 rows an op -- or a whole GROUP of ops over one vec
+ *                     (sqllm_launch_group) -- is ONE launch of the split matrix-core kernel with its CSR / top-X workgroups in
+ *                     the same grid; 0: one launch per op plus a launch for its sparse terms (as from 17 rows on)
  *   "validate_csr"    debugging aid, default 0.  1 = before every launch that carries a CSR term,
  *                     check ON THE DEVICE that rows[] is non-decreasing with rows[0] == 0 and
  *                     rows[N] == nnz, and return SQLLM_E_SPARSE otherwise.  Blocks the host (one

@@ -167,7 +167,7 @@ void fill_segment(const sqllm_op* op, sqllm::Segment* sg) {
 // workgroups, none of them short (N / 64 is rarely a multiple of the CU count: cutting K slices per
 // column tile left the last round 27 % full on the 13B gate/up shape).  A range is a whole number
 // of workgroup steps (waves x 4 units); one that crosses a tile boundary costs a second piece.
-void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm) {
+void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1) {
   make_plan(op, gm, 1);
   const int mb = sqllm::mfma_row_blocks(gm->batch);
   const int grid_y = (gm->batch + 16 * mb - 1) / (16 * mb);
@@ -178,6 +178,7 @@ void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm) {
   if (upw <= 0) {
     int target = knobs().target_wgs.load(std::memory_order_relaxed);
     if (target <= 0) target = (mb == 4 ? 1 : 2) * cu_count();
+    target = (target + ops_in_launch - 1) / ops_in_launch;  // the ops of a group share the launch's workgroups
     long long ranges = (target + grid_y - 1) / grid_y;
     if (ranges < 1) ranges = 1;
     upw = (total_units + ranges - 1) / ranges;
@@ -202,7 +203,7 @@ void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm) {
 
 int mfma_min_batch_of(const sqllm_op* op) {
   const int v = knobs().mfma_min_batch.load(std::memory_order_relaxed);
-  return v > 0 ? v : (op->bits == 3 ? 17 : 9);
+  return v > 0 ? v : 9;  // (3-bit: 17 until round 4 -- from 9 rows the fused small-batch launch of the split matrix-core kernel beats the column-lane kernel: 13B s45 layer 191-226 vs 270-286 us at 9-16 rows)
 }
 int cols_max_batch_of(const sqllm_op* op) {
   const int v = knobs().cols_max_batch.load(std::memory_order_relaxed);
@@ -325,6 +326,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "scratch_in_capture")) { knobs().scratch_in_capture.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { knobs().validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "mfma_split")) { knobs().mfma_split.store(value ? 1 : 0); return SQLLM_OK; }
+  if (!strcmp(name, "mfma_fuse_small")) { knobs().mfma_fuse_small.store(value ? 1 : 0); return SQLLM_OK; }
   if (g_experimental.set_option) return g_experimental.set_option(name, value);  // (measurement library)
   return SQLLM_E_OPTION;
 }
@@ -343,6 +345,7 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "scratch_in_capture")) { *value = knobs().scratch_in_capture.load(); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { *value = knobs().validate_csr.load(); return SQLLM_OK; }
   if (!strcmp(name, "mfma_split")) { *value = knobs().mfma_split.load(); return SQLLM_OK; }
+  if (!strcmp(name, "mfma_fuse_small")) { *value = knobs().mfma_fuse_small.load(); return SQLLM_OK; }
   if (g_experimental.get_option) return g_experimental.get_option(name, value);  // (measurement library)
   return SQLLM_E_OPTION;
 }
@@ -377,6 +380,50 @@ int64_t sqllm_linear_workspace_bytes(const sqllm_op* op) {
   if (!op || op->N <= 0) return 0;
   return align16(8ll * (op->batch <= 0 ? 1 : op->batch) * op->N);
 }
+
+// Batched ops with a CSR term want vec TRANSPOSED (xT[k][row]: one coalesced read per non-zero serves every batch
+// row, instead of `batch` gathers 4 K bytes apart).  The copy lives in stream-ordered scratch (hipMallocAsync /
+// hipFreeAsync on the caller's stream: no host synchronisation, the pool keeps the block for the next call; inside a
+// stream capture the allocation and the free become memory nodes of the graph -- works under torch's graph capture
+// on ROCm 7.2; option scratch_in_capture = 0 keeps captures allocation-free).  Without scratch the role falls back
+// to gathering from vec itself.
+struct TransposedVec {
+  float* xT = nullptr;
+  int Bp = 0;
+  hipStream_t s = nullptr;
+  // enqueues the transpose of ops[0].vec if any op of the group has a CSR term and scratch can be had; *e0 (the
+  // start event of a profiled group) goes to the transpose kernel if there is one
+  int acquire(const sqllm_op* ops, int n, sqllm_stream_t stream, hipEvent_t* e0) {
+    s = static_cast<hipStream_t>(stream);
+    bool any_csr = false;
+    for (int i = 0; i < n; ++i) any_csr = any_csr || (ops[i].nnz > 0 && ops[i].rows && ops[i].cols && ops[i].vals);
+    if (!any_csr || !ops[0].vec || ops[0].batch <= 0 || ops[0].K <= 0 || !knobs().sparse_transpose.load(std::memory_order_relaxed))
+      return SQLLM_OK;
+    if (!knobs().scratch_in_capture.load(std::memory_order_relaxed)) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (!(hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone)) {
+        (void)hipGetLastError();
+        return SQLLM_OK;
+      }
+    }
+    Bp = (ops[0].batch + 63) / 64 * 64;
+    keep_scratch_in_pool();
+    void* p = nullptr;
+    if (hipMallocAsync(&p, (size_t)ops[0].K * Bp * sizeof(float), s) != hipSuccess || !p) {
+      (void)hipGetLastError();  // no scratch: gather from vec
+      Bp = 0;
+      return SQLLM_OK;
+    }
+    xT = static_cast<float*>(p);
+    const hipError_t e = sqllm::transpose_vec(ops[0].vec, xT, ops[0].batch, ops[0].K, Bp, s, e0 ? *e0 : nullptr);
+    if (e != hipSuccess) return static_cast<int>(e);  // (the destructor frees)
+    if (e0) *e0 = nullptr;  // (a profiled group starts with its transpose)
+    return SQLLM_OK;
+  }
+  ~TransposedVec() {
+    if (xT) (void)hipFreeAsync(xT, s);
+  }
+};
 
 // One kernel over 1..kMaxSegments ops that share vec, K, bits and batch.  `lin` (optional) points at
 // the fused-linear descriptors the ops were taken from: `ops` is then lin[i].op.
@@ -420,6 +467,36 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
     return static_cast<int>(sqllm::launch_batched_cols(ops[0].bits, a, static_cast<hipStream_t>(stream)));
   }
+  if (!lin && takes_mfma_path(&ops[0]) && ops[0].batch <= sqllm::kSmallSplitRows && knobs().mfma_split.load(std::memory_order_relaxed) &&
+      knobs().mfma_fuse_small.load(std::memory_order_relaxed)) {
+    // up to 16 rows on the split matrix-core kernel: ONE launch for the whole group, sparse roles included
+    sqllm::LaunchArgs a;
+    a.ev_start = e0;
+    a.ev_stop = e1;
+    a.x = ops[0].vec;
+    a.ga.n_seg = n;
+    memset(a.ga.seg, 0, sizeof(a.ga.seg));
+    int block = 0;
+    for (int i = 0; i < n; ++i) {
+      const sqllm_op* op = &ops[i];
+      int rc = validate(op);
+      if (rc == SQLLM_OK) rc = validate_csr_values(op, stream);
+      if (rc != SQLLM_OK) return rc;
+      if (op->vec != ops[0].vec || op->K != ops[0].K || op->bits != ops[0].bits || op->batch != ops[0].batch) return SQLLM_E_GROUP;
+      if ((uint64_t)op->batch * (uint64_t)op->K >= (1ull << 31)) return SQLLM_E_SHAPE;  // 32-bit row offsets into vec
+      sqllm::Segment& sg = a.ga.seg[i];
+      fill_segment(op, &sg);
+      make_plan_mfma(op, &sg.gm, n);
+      a.ga.block0[i] = block;
+      block += (sg.gm.dense_block0 + sg.gm.dense_blocks + 7) / 8 * 8;
+    }
+    for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
+    // (The CSR chunks gather from vec itself here.  Handing them a transposed copy -- TransposedVec, as the wider
+    // batches get -- was measured: no faster at 8 / 16 rows in the sum of the kernels (13B s45 layer 168 vs 155 us at 8
+    // rows), and inside a captured graph the scratch's allocation / free nodes cost ~25 us per group: 258 vs 150 us per
+    // layer.  profiles/r04_small_batch_layer.txt)
+    return static_cast<int>(sqllm::launch_small_split(ops[0].bits, a, static_cast<hipStream_t>(stream)));
+  }
   if (!lin && (takes_mfma_path(&ops[0]) || (n == 1 && takes_cols_path(&ops[0])))) {
     // batched operators: one launch per op (the members of a group only share their input) of the
     // matrix-core kernel (wide batches) or of the column-lane kernel (small ones)
@@ -428,39 +505,13 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     // read per non-zero instead of `batch` gathers).  The copy lives in stream-ordered scratch
     // (hipMallocAsync / hipFreeAsync on the caller's stream: no host synchronisation, the pool keeps
     // the block for the next call).  Without scratch the role falls back to gathering from vec itself.
-    float* xT = nullptr;
-    int Bp = 0;
-    bool any_csr = false;
-    for (int i = 0; i < n; ++i) any_csr = any_csr || (ops[i].nnz > 0 && ops[i].rows && ops[i].cols && ops[i].vals);
-    if (mfma && any_csr && ops[0].vec && ops[0].batch > 0 && ops[0].K > 0 && knobs().sparse_transpose.load(std::memory_order_relaxed)) {
-      // (inside a stream capture the allocation and the free become memory nodes of the graph -- works under
-      // torch's graph capture on ROCm 7.2; option scratch_in_capture = 0 keeps captures allocation-free)
-      bool scratch_ok = true;
-      if (!knobs().scratch_in_capture.load(std::memory_order_relaxed)) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        scratch_ok = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
-      }
-      if (scratch_ok) {
-        Bp = (ops[0].batch + 63) / 64 * 64;
-        keep_scratch_in_pool();
-        void* p = nullptr;
-        if (hipMallocAsync(&p, (size_t)ops[0].K * Bp * sizeof(float), static_cast<hipStream_t>(stream)) == hipSuccess && p) {
-          xT = static_cast<float*>(p);
-          hipError_t e = sqllm::transpose_vec(ops[0].vec, xT, ops[0].batch, ops[0].K, Bp, static_cast<hipStream_t>(stream), e0);
-          if (e == hipSuccess) e0 = nullptr;  // (a profiled group starts with its transpose)
-          if (e != hipSuccess) { (void)hipFreeAsync(p, static_cast<hipStream_t>(stream)); return static_cast<int>(e); }
-        } else {
-          (void)hipGetLastError();  // no scratch: gather from vec
-          Bp = 0;
-        }
-      } else {
-        (void)hipGetLastError();
-      }
+    TransposedVec tv;
+    if (mfma) {
+      const int rc = tv.acquire(ops, n, stream, &e0);
+      if (rc != SQLLM_OK) return rc;
     }
-    struct ScratchGuard {
-      float* p; hipStream_t s;
-      ~ScratchGuard() { if (p) (void)hipFreeAsync(p, s); }
-    } guard{xT, static_cast<hipStream_t>(stream)};
+    float* const xT = tv.xT;
+    const int Bp = tv.Bp;
     for (int i = 0; i < n; ++i) {
       const sqllm_op* op = &ops[i];
       int rc = validate(op);

@@ -23,7 +23,7 @@ struct Knobs {
   // Routing of the *_batched operators by batch size (0 = the measured defaults, which depend on the bit width:
   // 13B gate/up shape, profiles/r02_batch_paths_*.txt):
   //   4-bit: 2..4 rows column-lane kernel, 5..8 batch tiles of the batch-1 kernel, 9+ matrix cores
-  //   3-bit: 2..16 rows column-lane kernel (two passes from 9 rows), 17+ matrix cores
+  //   3-bit: 2..8 rows column-lane kernel, 9+ matrix cores
   std::atomic<int> mfma_min_batch{0};  // rows from which the matrix-core kernel takes over
   std::atomic<int> cols_min_batch{0};  // the column-lane kernel serves cols_min_batch .. cols_max_batch rows (0 = default: 2)
   std::atomic<int> cols_max_batch{0};
@@ -31,6 +31,7 @@ struct Knobs {
   std::atomic<int> sparse_transpose{1};  // wide batches: the CSR role reads a transposed copy of vec (stream-ordered scratch)
   std::atomic<int> validate_csr{0};    // debug: check rows[] on the device before every launch that carries a CSR term
   std::atomic<int> mfma_split{1};      // wide batches: bf16 matrix instructions on exactly split operands (0: the fp32 matrix instruction)
+  std::atomic<int> mfma_fuse_small{1};  // ... and up to 16 rows: the group's ops with their sparse terms as ONE launch of that kernel
 };
 constexpr int kMaxDevices = 32;
 

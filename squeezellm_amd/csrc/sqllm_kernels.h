@@ -150,6 +150,8 @@ hipError_t launch_stream(int bits, const StreamArgs& sa, const GroupArgs& ga, hi
 hipError_t launch_batched_mfma(int bits, const LaunchArgs& a, hipStream_t stream);        // fp32 matrix instructions
 hipError_t launch_batched_mfma_split(int bits, const LaunchArgs& a, hipStream_t stream);  // bf16 matrix instructions on exactly split operands (sqllm_mfma_split.hip)
 hipError_t launch_batched_cols(int bits, const LaunchArgs& a, hipStream_t stream);
+constexpr int kSmallSplitRows = 16;  // rows up to which a group of ops runs as ONE launch on the split matrix-core kernel (all three terms)
+hipError_t launch_small_split(int bits, const LaunchArgs& a, hipStream_t stream);
 hipError_t transpose_vec(const float* x, float* xT, int batch, int K, int Bp, hipStream_t stream, hipEvent_t ev_start);
 hipError_t launch_batched_sparse(const LaunchArgs& a, hipStream_t stream);
 hipError_t check_csr(const int* rows, int N, int nnz, hipStream_t stream, int* bad);

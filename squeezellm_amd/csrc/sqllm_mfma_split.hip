@@ -39,6 +39,7 @@
 #include "sqllm_kernels.h"
 
 #include "sqllm_decode.h"
+#include "sqllm_roles.h"
 
 namespace sqllm {
 
@@ -353,6 +354,53 @@ sqllm_fused_batched_split(const float* x, const GroupArgs ga) {
                                          lds);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Up to 16 rows: ONE launch for 1..kMaxSegments ops over one vec, all three terms -- the grid of the batch-1 fused
+// kernel (per op [CSR chunks | top-X slabs | pad to x8 | dense ranges]) with the split matrix-core role as its dense
+// role.  (From 17 rows on the sparse terms are a launch of their own, as for the fp32 kernel: sqllm_sparse_batched.)
+// The reference runs 1-3 dependent launches per op and one weight pass per batch row
+// (squeezellm/quant_cuda_kernel.cu:580-657, :661-738).
+// ------------------------------------------------------------------------------------------------
+constexpr int kSmallRows = 16;
+
+template <int BITS, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 4)
+sqllm_fused_small_split(const float* x, const GroupArgs ga, const float* xT, int Bp) {
+  constexpr int T = WAVES * 64;
+  // (the transposed-vec CSR role lays its LDS out for up to 64 rows: sqllm_roles.h, csr_role XTMODE)
+  __shared__ __attribute__((aligned(16))) float lds[cmax(split_lds_floats(BITS, WAVES),
+                                                         cmax(kCsrSpanMax + cmax(kCsrSpanMax, 64 * (kCsrXtSpan + 1) + 3 * kCsrChunk), kTopxLds))];
+  // one round of scalar loads for the block table and segment 0 (see sqllm_fused_matvec)
+  Segment sg = ga.seg[0];
+  const int n_seg = ga.n_seg, blk1 = ga.block0[1], blk2 = ga.block0[2], blk3 = ga.block0[3];
+  asm volatile("" ::SQLLM_SEG_OPERANDS(sg), "s"(x), "s"(n_seg), "s"(blk1), "s"(blk2), "s"(blk3));
+  __builtin_amdgcn_sched_barrier(0);
+  int s = 0, base = 0;
+  if (n_seg > 1 && (int)blockIdx.x >= blk1) { s = 1; base = blk1; }
+  if (n_seg > 2 && (int)blockIdx.x >= blk2) { s = 2; base = blk2; }
+  if (n_seg > 3 && (int)blockIdx.x >= blk3) { s = 3; base = blk3; }
+  s = __builtin_amdgcn_readfirstlane(s);
+  if (s != 0) {
+    sg = ga.seg[s];
+    asm volatile("" ::SQLLM_SEG_OPERANDS(sg));
+  }
+  const KernelGeom& gm = sg.gm;
+  const int bid = blockIdx.x - base;
+  const int d = bid - gm.dense_block0;
+  if (d >= 0 && d < gm.dense_blocks) {
+    dense_role_mfma_split<BITS, 1, WAVES>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, gm.batch, 0, d, gm.col_tiles,
+                                          gm.units_total, gm.units_per_wg,
+                                          gm.dense_blocks == gm.col_tiles * gm.k_slices ? gm.k_slices * gm.units_per_wg : gm.units_total, lds);
+  } else if (bid < gm.csr_blocks) {
+    // vec transposed (xT[k][row], written by sqllm_transpose_vec just before this launch): ONE 64-byte read per non-zero
+    // serves all the rows; without scratch, gathers from vec itself, one per non-zero and row
+    if (xT) csr_role<T, 1, float, float, true>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, 0, gm.batch, bid, lds, nullptr, 0, xT, Bp);
+    else csr_role<T, kSmallRows, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, 0, gm.batch, bid, lds, nullptr, 0);
+  } else if (bid < gm.csr_blocks + gm.topx_blocks) {
+    topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, 0, gm.batch, bid - gm.csr_blocks, lds);
+  }
+}
+
 template <int BITS, int MB>
 hipError_t launch_split_inst(const LaunchArgs& a, hipStream_t stream) {
   const KernelGeom& gm = a.ga.seg[0].gm;
@@ -374,6 +422,23 @@ hipError_t launch_split_bits(const LaunchArgs& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+// 1..kMaxSegments ops over one vec (a.ga), up to kSmallRows rows: all three terms of every op in one launch
+hipError_t launch_small_split(int bits, const LaunchArgs& a, hipStream_t stream) {
+  if (a.ga.seg[0].gm.batch > kSmallRows) return hipErrorInvalidValue;
+  dim3 grid(a.ga.block0[a.ga.n_seg]);
+  const float* x = static_cast<const float*>(a.x);
+  if (bits == 4) {
+    auto kern = sqllm_fused_small_split<4, kWaves>;
+    if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga, a.xT, a.Bp);
+    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga, a.xT, a.Bp);
+  } else {
+    auto kern = sqllm_fused_small_split<3, kWaves>;
+    if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga, a.xT, a.Bp);
+    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga, a.xT, a.Bp);
+  }
+  return hipGetLastError();
+}
 
 // one op (a.ga.seg[0]), operator ABI, batch rows through the bf16 matrix cores with split operands (dense term only)
 hipError_t launch_batched_mfma_split(int bits, const LaunchArgs& a, hipStream_t stream) {

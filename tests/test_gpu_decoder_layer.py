@@ -87,7 +87,7 @@ def test_llama7b_decoder_layer_grouped(gpu, bits, sparse, topX):
     _check_layer(layers, gpu, batch=0, graph=True)
 
 
-@pytest.mark.parametrize("batch", [1, 2, 4, 8])
+@pytest.mark.parametrize("batch", [1, 2, 4, 8, 12, 16])
 def test_llama13b_decoder_layer_grouped_batched(gpu, batch):
     """BASELINE configs[3]: 13B shapes, w4 s45, the *_batched operators at 1 / 2 / 4 / 8 rows, grouped
     (q/k/v and gate/up groups stay one launch of the batch tiles; o_proj / down_proj alone take the
@@ -99,3 +99,20 @@ def test_llama13b_decoder_layer_grouped_batched(gpu, batch):
 def test_llama13b_decoder_layer_w3_batch4(gpu):
     layers = _decoder_layer("llama-13b", 3, 0.0045, 10, gpu, seed0=1350)
     _check_layer(layers, gpu, batch=4, graph=False)
+
+
+@pytest.mark.parametrize("bits", [4, 3])
+@pytest.mark.parametrize("batch", [5, 8, 13])
+def test_llama13b_decoder_layer_small_split_groups(gpu, bits, batch):
+    """Up to 16 rows a GROUP of ops (q/k/v, gate/up) is one launch of the split matrix-core kernel with the CSR chunks
+    and top-X slabs of every op in the same grid (csrc/sqllm_mfma_split.hip: sqllm_fused_small_split); forced from 5
+    rows up here, whatever the router's default switch-over is."""
+    from squeezellm_amd import _lib
+
+    layers = _decoder_layer("llama-13b", bits, 0.0045, 10, gpu, seed0=1400 + bits)
+    before = _lib.get_option("mfma_min_batch")
+    _lib.set_option("mfma_min_batch", 5)
+    try:
+        _check_layer(layers, gpu, batch=batch, graph=False)
+    finally:
+        _lib.set_option("mfma_min_batch", before)
