@@ -213,6 +213,7 @@ class ColumnParallelPass:
         from .decode import OpSequence
 
         self.rank, self.world, self.group, self.device = rank, world_size, group, device
+        self._flat = hasattr(dist, "all_gather_into_tensor") and (dist.get_backend(group) != "gloo" if dist.is_initialized() else True)
         # launch groups = runs of consecutive linears reading the same input tensor (up to 4)
         groups, cur = [], []
         for i, x in enumerate(xs):
@@ -225,21 +226,29 @@ class ColumnParallelPass:
         if cur:
             groups.append(cur)
         self.groups = groups
-        self.local, self.gathered, self.seqs, self.widths = [], [], [], []
-        for grp in groups:
+        # Every group's gather buffer [world, W] is a view of ONE arena, and this rank's kernels accumulate straight into
+        # ITS row of that buffer (the in-place form of the all-gather: input = output[rank]): no per-group staging
+        # buffer, no per-group memset, no hand-over copy -- one memset of the arena per pass is all the `mul += ...`
+        # semantics need.  (With a staging buffer, a memset and a copy per group the one-rank pass ran 30 % below the
+        # replica line before any collective: 626 vs 897 tokens/s on 7b-w4-s0, round 3.)
+        self.widths = [[max(b - a for a, b in column_ranges(layers[i]["N"], world_size)) for i in grp] for grp in groups]
+        sizes = [world_size * sum(w) for w in self.widths]
+        self.arena = torch.zeros(max(sum(sizes), 1), device=device, dtype=torch.float32)
+        self.local, self.gathered, self.seqs = [], [], []
+        at = 0
+        for grp, widths, size in zip(groups, self.widths, sizes):
+            full = self.arena[at:at + size].view(world_size, sum(widths))
+            at += size
+            mine = full[rank]
             shards = [shard_layer_columns(layers[i], rank, world_size) for i in grp]
-            # every rank's slice of linear i is padded to the widest rank's, so that the collective is uniform
-            widths = [max(b - a for a, b in column_ranges(layers[i]["N"], world_size)) for i in grp]
-            mine = torch.zeros(sum(widths), device=device, dtype=torch.float32)
             ys, off = [], 0
-            for sh, w in zip(shards, widths):
+            for sh, w in zip(shards, widths):  # (every rank's slice of a linear is padded to the widest rank's: the collective is uniform)
                 ys.append(mine[off:off + sh["N"]])
                 off += w
             live = [(sh, xs[i], y) for sh, i, y in zip(shards, grp, ys) if sh["N"] > 0]
             self.seqs.append(OpSequence([t[0] for t in live], [t[1] for t in live], [t[2] for t in live], fuse_shared_input=True) if live else None)
             self.local.append(mine)
-            self.gathered.append(torch.zeros((world_size, sum(widths)), device=device, dtype=torch.float32))
-            self.widths.append(widths)
+            self.gathered.append(full)
         self.graph = None
         if graph and torch.device(device).type == "cuda":
             try:
@@ -257,14 +266,15 @@ class ColumnParallelPass:
                 torch.cuda.synchronize(device)
 
     def _eager(self) -> None:
+        self.arena.zero_()  # (operator semantics: mul += ...; once per pass, every group's slices at once)
         for seq, mine, full in zip(self.seqs, self.local, self.gathered):
-            mine.zero_()  # (operator semantics: mul += ...)
             if seq is not None:
                 seq.launch()
-            if self.world == 1:
-                full[0].copy_(mine)
-            else:
-                dist.all_gather_into_tensor(full, mine, group=self.group)
+            if self.world > 1:
+                if self._flat:
+                    dist.all_gather_into_tensor(full, mine, group=self.group)  # in place: mine IS full[rank]
+                else:  # gloo: list form (it copies the input into its own slot: a no-op move onto itself)
+                    dist.all_gather(list(full.unbind(0)), mine.clone(), group=self.group)
 
     def step(self) -> None:
         if self.graph is not None:

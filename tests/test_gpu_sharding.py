@@ -87,3 +87,29 @@ def test_ring_pipeline_whole_tick_capture_matches_eager(gpu):
     assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
     # fp32 atomics: summation order may differ between the two runs; one fp16 ulp of slack
     assert torch.allclose(outs[0], outs[1], rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("mode,env", [("columns", {}), ("pipeline", {}), ("pipeline", {"SQLLM_PIPELINE_CAPTURE": "1"})],
+                         ids=["columns", "pipeline-eager-collective", "pipeline-tick-captured"])
+def test_bench_distributed_modes_run_on_one_rccl_rank(gpu, mode, env):
+    """bench.py's N > 1 modes with a real RCCL process group of ONE rank (SQLLM_BENCH_FORCE_DIST=1): init, the collective
+    per launch group / per tick (captured into the tick's graph, and eager), barrier + MAX reduction of the timings, the
+    JSON line -- so that the driver's first 8-GPU run is not also the first run of this code."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    e = dict(os.environ, SQLLM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + hash((mode, tuple(env))) % 300),
+             RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", **env)
+    cmd = [sys.executable, os.path.join(H.ROOT, "bench.py"), "--gpus", "1", "--parallel", mode, "--config", "7b-w4-s45", "--layers", "3",
+           "--steps", "4", "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--no-roofline", "--no-sub-records"]
+    r = subprocess.run(cmd, cwd=H.ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["rccl_ranks"] == 1
+    assert line["scaling"] == "strong" and line["steps"] == 4
+    if mode == "pipeline":
+        assert line["pipeline_tick_captured"] is True  # (one rank: the whole tick is always captured)
+    else:
+        assert line["column_parallel"]["graph_captured"] in (True, False)
