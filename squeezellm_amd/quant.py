@@ -189,25 +189,28 @@ class QuantLinearLUTFused(QuantLinearLUT):
         self.__dict__["_folded"] = (key, out)
         return out
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if x.dtype != torch.float16 or not x.is_cuda:
-            return super().forward(x)
+    def _descriptor(self, batch: int, dev: int, stream: int):
+        """The pre-marshalled sqllm_linear of this module for (batch, device, stream): every persistent field filled in
+        once -- weights, codebook, the (folded) sparse operands, bias, workspace -- and re-used call after call; only
+        vec / mul change per call.  Rebuilt when a buffer is replaced or written in place (object identity + version
+        counter of every buffer it was built from)."""
+        # (straight from the module's buffer dict: nn.Module.__getattr__ costs ~0.5 us per buffer, ten times a dict lookup)
+        bufs = self.__dict__["_buffers"]
+        key = tuple((id(t), t._version) for t in bufs.values() if t is not None)
+        cache = self.__dict__.setdefault("_desc", {})
+        hit = cache.get((batch, dev, stream))
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        capturing = torch.cuda.is_current_stream_capturing()
         K, N = self.infeatures, self.outfeatures
-        if x.shape[-1] != K:
-            raise ValueError(f"last dimension of x must be {K}, got {tuple(x.shape)}")
-        x2 = x.reshape(-1, K)
-        if not x2.is_contiguous():
-            x2 = x2.contiguous()
-        rows = x2.shape[0]
-        batch = 0 if rows == 1 else rows
-        out = torch.empty((rows, N), dtype=torch.float16, device=x.device)
         lin = _lib.SqllmLinear()
         o = lin.op
         o.bits, o.batch, o.K, o.N = self.bits, batch, K, N
-        o.vec, o.qweight, o.mul, o.lookup_table = x2.data_ptr(), self.qweight.data_ptr(), out.data_ptr(), self.lookup_table.data_ptr()
+        o.qweight, o.lookup_table = self.qweight.data_ptr(), self.lookup_table.data_ptr()
         if self.include_sparse and self.numvals > 0:
             self._check_csr_once()
         folded = self._csr_with_topx() if self.include_sparse and self.topX > 0 and self.fold_topx else None
+        keep = [folded]
         if folded is not None:  # one CSR term that contains the top-X rows (decode.fold_topx_into_csr)
             if folded[2].numel():
                 o.rows, o.cols, o.vals, o.nnz = folded[0].data_ptr(), folded[1].data_ptr(), folded[2].data_ptr(), folded[2].numel()
@@ -217,8 +220,29 @@ class QuantLinearLUTFused(QuantLinearLUT):
             if self.include_sparse and self.topX > 0:  # independent of the CSR term (which may be empty)
                 o.full_rows, o.full_row_indices, o.topX = self.full_rows.data_ptr(), self.full_row_indices.data_ptr(), self.topX
         lin.bias = None if self.bias is None else self.bias.data_ptr()
-        lin.workspace = self._workspace(batch, x.device).data_ptr()
-        quant_cuda._launch(quant_cuda._fn("sqllm_linear_f16"), x.get_device(), (ctypes.byref(lin),))
+        ws = self._workspace(batch, self.qweight.device)
+        lin.workspace = ws.data_ptr()
+        entry = (key, (lin, ctypes.byref(lin), ws, keep))
+        # (while a stream is capturing, the folded CSR and the CSR check are deferred: do not pin that state)
+        if not (capturing and self.include_sparse):
+            cache[(batch, dev, stream)] = entry
+        return entry[1]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dtype is not torch.float16 or not x.is_cuda:
+            return super().forward(x)
+        K, N = self.infeatures, self.outfeatures
+        if x.shape[-1] != K:
+            raise ValueError(f"last dimension of x must be {K}, got {tuple(x.shape)}")
+        x2 = x if x.dim() == 2 else x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        dev = x.get_device()
+        out = torch.empty((rows, N), dtype=torch.float16, device=x.device)
+        lin, ref, _ws, _keep = self._descriptor(0 if rows == 1 else rows, dev, quant_cuda._raw_stream(dev))
+        lin.op.vec, lin.op.mul = x2.data_ptr(), out.data_ptr()
+        quant_cuda._launch(quant_cuda._fn("sqllm_linear_f16"), dev, (ref,))
         return out.reshape(*x.shape[:-1], N)
 
 
