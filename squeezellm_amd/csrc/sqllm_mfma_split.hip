@@ -339,6 +339,8 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
   }  // pieces
 }
 
+}  // namespace
+
 template <int BITS, int MB, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, (MB == 1 || (BITS == 4 && MB == 2)) ? 4 : 2)
 sqllm_fused_batched_split(const float* x, const GroupArgs ga) {
@@ -400,6 +402,8 @@ sqllm_fused_small_split(const float* x, const GroupArgs ga, const float* xT, int
     topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, 0, gm.batch, bid - gm.csr_blocks, lds);
   }
 }
+
+namespace {
 
 template <int BITS, int MB>
 hipError_t launch_split_inst(const LaunchArgs& a, hipStream_t stream) {
