@@ -35,20 +35,21 @@ Knobs& knobs() { return g_knobs[device_slot()]; }
 // op needs (2048 rows x K = 22016 floats is 180 MB).
 static void keep_scratch_in_pool() {
   static std::atomic<unsigned> done{0};
+  if (!knobs().scratch_pool_threshold.load(std::memory_order_relaxed)) return;  // opted out: the pool is left as the application set it
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) { (void)hipGetLastError(); return; }
   const unsigned bit = 1u << dev;
   if (done.load(std::memory_order_relaxed) & bit) return;
-  done.fetch_or(bit, std::memory_order_relaxed);
   hipMemPool_t pool = nullptr;
-  if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess || !pool) { (void)hipGetLastError(); return; }
+  if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess || !pool) { (void)hipGetLastError(); return; }  // (retried on the next call)
   uint64_t cur = 0;
   const uint64_t want = 256ull << 20;
   if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &cur) != hipSuccess) { (void)hipGetLastError(); cur = 0; }
   if (cur < want) {
     uint64_t v = want;
-    if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &v) != hipSuccess) (void)hipGetLastError();
+    if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &v) != hipSuccess) { (void)hipGetLastError(); return; }  // (retried)
   }
+  done.fetch_or(bit, std::memory_order_relaxed);  // only once it has succeeded
 }
 
 int cu_count() {
@@ -247,8 +248,9 @@ void make_plan_cols(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch
   if (upw > 0x3fffffff) upw = 0x3fffffff / sqllm::kWaves * sqllm::kWaves;
   gm->units_per_wg = (int)upw;
   gm->k_slices = (int)((gm->units_total + upw - 1) / upw);
-  // (the kernel recognises the tile-aligned cut by dense_blocks == col_tiles * k_slices -- which, when it holds
-  // for a contiguous cut too, describes the same ranges)
+  // (the kernel recognises the tile-aligned cut by dense_blocks == col_tiles * k_slices; a contiguous cut that happens
+  // to satisfy the same equation is then READ as tile-aligned -- ranges of units_per_wg units that restart at every
+  // tile -- which covers every unit exactly once as well: tests/test_capi_cpu.py fuzzes both readings)
   gm->dense_blocks = aligned ? gm->col_tiles * gm->k_slices : (int)((total_units + upw - 1) / upw);
   gm->sparse_last = 0;
   gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
@@ -327,6 +329,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "validate_csr")) { knobs().validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "mfma_split")) { knobs().mfma_split.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "mfma_fuse_small")) { knobs().mfma_fuse_small.store(value ? 1 : 0); return SQLLM_OK; }
+  if (!strcmp(name, "scratch_pool_threshold")) { knobs().scratch_pool_threshold.store(value ? 1 : 0); return SQLLM_OK; }
   if (g_experimental.set_option) return g_experimental.set_option(name, value);  // (measurement library)
   return SQLLM_E_OPTION;
 }
@@ -346,6 +349,7 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "validate_csr")) { *value = knobs().validate_csr.load(); return SQLLM_OK; }
   if (!strcmp(name, "mfma_split")) { *value = knobs().mfma_split.load(); return SQLLM_OK; }
   if (!strcmp(name, "mfma_fuse_small")) { *value = knobs().mfma_fuse_small.load(); return SQLLM_OK; }
+  if (!strcmp(name, "scratch_pool_threshold")) { *value = knobs().scratch_pool_threshold.load(); return SQLLM_OK; }
   if (g_experimental.get_option) return g_experimental.get_option(name, value);  // (measurement library)
   return SQLLM_E_OPTION;
 }
@@ -431,9 +435,9 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
                                     hipEvent_t e1, const sqllm_linear* lin = nullptr) {
   if (n < 1 || n > sqllm::kMaxSegments) return SQLLM_E_GROUP;
   if (!ops && !lin) return SQLLM_E_NULL;
-  // (the column-lane kernel only for an op that is alone in its launch: q/k/v or gate/up sharing one
-  // launch of the batch tiles beat three / two launches of it -- 13B s45 decoder layer at 2 rows:
-  // 88 vs 101 us)
+  // (small batches: a group whose summed columns pass the column-lane kernel's test takes that kernel as ONE launch --
+  // make_plan_cols divides the workgroup target by the number of ops; other groups stay on the batch tiles, which beat
+  // one column-lane launch per op -- 13B s45 decoder layer at 2 rows: 88 vs 101 us)
   if (!lin && n > 1 && knobs().cols_groups.load(std::memory_order_relaxed) && group_takes_cols_path(ops, n)) {
     // a group on the column-lane kernel: ONE launch, the workgroups divided between the ops
     sqllm::LaunchArgs a;

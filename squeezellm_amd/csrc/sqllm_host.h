@@ -31,6 +31,7 @@ struct Knobs {
   std::atomic<int> sparse_transpose{1};  // wide batches: the CSR role reads a transposed copy of vec (stream-ordered scratch)
   std::atomic<int> validate_csr{0};    // debug: check rows[] on the device before every launch that carries a CSR term
   std::atomic<int> mfma_split{1};      // wide batches: bf16 matrix instructions on exactly split operands (0: the fp32 matrix instruction)
+  std::atomic<int> scratch_pool_threshold{1};  // 0: never touch the release threshold of the device's default memory pool
   std::atomic<int> mfma_fuse_small{1};  // ... and up to 16 rows: the group's ops with their sparse terms as ONE launch of that kernel
 };
 constexpr int kMaxDevices = 32;
