@@ -297,8 +297,10 @@ int sqllm_set_option(const char* name, int value);
 int sqllm_get_option(const char* name, int* value);
 
 /* Geometry the library would use for this op launched ALONE (sqllm_launch / the operator names).  Ops
- * that share a launch (sqllm_launch_group) are planned with other workgroup counts, and the
- * column-lane kernel is only taken by an op that is alone in its launch. */
+ * that share a launch (sqllm_launch_group) are planned with other workgroup counts (the launch's
+ * workgroup target is divided between them), on the kernel the GROUP routes to: the batch tiles, the
+ * column-lane kernel (judged by the sum of the group's columns, option "cols_groups") or, from
+ * mfma_min_batch up to 16 rows, the split matrix-core kernel. */
 typedef struct sqllm_plan {
   int32_t col_tiles, k_slices, groups_per_wave, dense_blocks, csr_blocks, topx_blocks, grid_x, grid_y;
 } sqllm_plan;
