@@ -47,6 +47,31 @@ def test_wide_batches_vs_oracle(qc, gpu, bits, K, N, kind, batch):
     assert H.rel_err(got, H.oracle_ref(case, x, mul, kind)) <= TOL_FP64
 
 
+@pytest.mark.parametrize("options", [dict(mfma_split=0), dict(mfma_fuse_small=0), dict(mfma_split=0, mfma_fuse_small=0)],
+                         ids=["fp32-instruction", "split-unfused", "fp32-unfused"])
+@pytest.mark.parametrize("bits,K,N", [(4, 1024, 132), (3, 1024, 776)])
+@pytest.mark.parametrize("batch", [9, 16, 40, 130])
+def test_wide_batch_routes_behind_options(qc, gpu, options, bits, K, N, batch):
+    """The routes the defaults no longer take stay correct: the fp32 matrix instruction (option mfma_split = 0: bit for bit an
+    fp32 FMA chain) and one launch per op + its sparse launch up to 16 rows (mfma_fuse_small = 0).  Also: the split kernel's
+    result agrees with the fp32 instruction's to fp32 round-off -- its operands are split exactly, six of nine partial
+    products kept (csrc/sqllm_mfma_split.hip)."""
+    from squeezellm_amd import _lib
+
+    case = H.make_case(bits, K, N, sparse=0.03, topX=3, heavy_rows=1, seed=bits * 100 + batch)
+    x, mul, want = run_batched(qc, gpu, case, "hybrid", batch)  # the default route
+    try:
+        for k, v in options.items():
+            _lib.set_option(k, v)
+        _, _, got = run_batched(qc, gpu, case, "hybrid", batch)
+    finally:
+        for k in options:
+            _lib.set_option(k, 1)
+    ref = H.oracle_ref(case, x, mul, "hybrid")
+    assert H.rel_err(got, ref) <= TOL_FP64
+    assert H.rel_err(got, want) <= 2e-6, "split operands vs fp32 matrix instruction / fused vs unfused launch"
+
+
 @pytest.mark.parametrize("bits", [3, 4])
 def test_ppl_eval_batch_2048(qc, gpu, bits):
     """B = 2048, the batch the reference's perplexity evaluation feeds the batched ops."""

@@ -16,7 +16,7 @@ CASE = st.fixed_dictionaries(dict(
     bits=st.sampled_from([3, 4]),
     K=st.integers(1, 40).map(lambda v: 32 * v),
     N=st.integers(1, 160).map(lambda v: 4 * v),
-    batch=st.sampled_from([0, 1, 2, 3, 5, 8, 11]),
+    batch=st.sampled_from([0, 1, 2, 3, 5, 8, 11, 13, 20, 40]),
     sparse=st.sampled_from([0.0, 0.0, 0.002, 0.02, 0.3]),
     topX=st.sampled_from([0, 0, 1, 3, 10]),
     target_wgs=st.sampled_from([0, 0, 1, 7, 64, 4096]),
