@@ -202,6 +202,45 @@ void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch
   gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
 }
 
+// Geometry of the WIDE matrix-core kernel (sqllm_mfma_split.hip: sqllm_fused_wide).  A UNIT is a block of 64 rows x a
+// group of 8 column tiles (one per wave).  Units are worked off one workgroup per CU at a time; as many whole rounds as
+// there are run every unit over ALL of K (no atomics, one table build); the units of the last, partial round are cut
+// into as many K slices as fill the idle CUs (their workgroups add atomically).  dense_blocks = workgroups of the 1-D
+// grid = full_units + (units - full_units) * k_slices; units_per_wg = units of K per slice.
+constexpr int kWideTiles = 8;
+constexpr int kWideMinBatch = 512;  // (13B shapes: from 512 rows the wide form wins -- 418 -> 299-360 us; at 128 rows it loses, 104 -> 158-169: profiles/r04_wide_first.txt)
+int make_plan_wide(const sqllm_op* op, sqllm::KernelGeom* gm) {  // returns full_units
+  make_plan(op, gm, 1);
+  const int row_blocks = (gm->batch + 63) / 64;
+  const int col_groups = (gm->col_tiles + kWideTiles - 1) / kWideTiles;
+  const long long units = (long long)col_groups * row_blocks;
+  const int cus = cu_count();
+  const long long full = units / cus * cus;
+  const long long rem = units - full;
+  int max_s = gm->units_total / (op->bits == 4 ? 32 : 8);  // a slice is at least 8 steps of 32 k's x 64 rows x 64 columns
+  if (max_s > sqllm::kMaxSlices) max_s = sqllm::kMaxSlices;
+  if (max_s < 1) max_s = 1;
+  int s = rem > 0 ? (int)(cus / rem) : 1;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  const int want = knobs().groups_per_wave.load(std::memory_order_relaxed) * 4;  // (option: units of K per slice, in groups of 4)
+  int upw = want > 0 ? want : ((gm->units_total + s - 1) / s + 3) / 4 * 4;
+  if (upw > gm->units_total) upw = (gm->units_total + 3) / 4 * 4;
+  gm->units_per_wg = upw;
+  gm->k_slices = (gm->units_total + upw - 1) / upw;
+  const long long blocks = full + rem * gm->k_slices;
+  gm->dense_blocks = blocks > 0x7fffffff ? 0x7fffffff : (int)blocks;
+  gm->sparse_last = 0;
+  gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
+  return (int)full;
+}
+
+bool takes_wide_path(const sqllm_op* op) {
+  int from = knobs().mfma_wide_min_batch.load(std::memory_order_relaxed);
+  if (from == 0) from = kWideMinBatch;
+  return op->batch >= from && knobs().mfma_split.load(std::memory_order_relaxed) != 0;
+}
+
 int mfma_min_batch_of(const sqllm_op* op) {
   const int v = knobs().mfma_min_batch.load(std::memory_order_relaxed);
   return v > 0 ? v : 9;  // (3-bit: 17 until round 4 -- from 9 rows the fused small-batch launch of the split matrix-core kernel beats the column-lane kernel: 13B s45 layer 191-226 vs 270-286 us at 9-16 rows)
@@ -328,6 +367,8 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "scratch_in_capture")) { knobs().scratch_in_capture.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { knobs().validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "mfma_split")) { knobs().mfma_split.store(value ? 1 : 0); return SQLLM_OK; }
+  if (!strcmp(name, "split_planes_min_batch")) { knobs().split_planes_min_batch.store(value); return SQLLM_OK; }
+  if (!strcmp(name, "mfma_wide_min_batch")) { knobs().mfma_wide_min_batch.store(value); return SQLLM_OK; }
   if (!strcmp(name, "mfma_fuse_small")) { knobs().mfma_fuse_small.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "scratch_pool_threshold")) { knobs().scratch_pool_threshold.store(value ? 1 : 0); return SQLLM_OK; }
   if (g_experimental.set_option) return g_experimental.set_option(name, value);  // (measurement library)
@@ -348,6 +389,8 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "scratch_in_capture")) { *value = knobs().scratch_in_capture.load(); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { *value = knobs().validate_csr.load(); return SQLLM_OK; }
   if (!strcmp(name, "mfma_split")) { *value = knobs().mfma_split.load(); return SQLLM_OK; }
+  if (!strcmp(name, "split_planes_min_batch")) { *value = knobs().split_planes_min_batch.load(); return SQLLM_OK; }
+  if (!strcmp(name, "mfma_wide_min_batch")) { *value = knobs().mfma_wide_min_batch.load(); return SQLLM_OK; }
   if (!strcmp(name, "mfma_fuse_small")) { *value = knobs().mfma_fuse_small.load(); return SQLLM_OK; }
   if (!strcmp(name, "scratch_pool_threshold")) { *value = knobs().scratch_pool_threshold.load(); return SQLLM_OK; }
   if (g_experimental.get_option) return g_experimental.get_option(name, value);  // (measurement library)
@@ -362,7 +405,9 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   if (op->K <= 0 || op->N <= 0 || (op->K % 32) != 0 || (op->N % 4) != 0) return SQLLM_E_SHAPE;
   sqllm::KernelGeom gm;
   const bool mfma = takes_mfma_path(op);
-  if (mfma) make_plan_mfma(op, &gm);
+  const bool wide = mfma && takes_wide_path(op);
+  if (wide) (void)make_plan_wide(op, &gm);
+  else if (mfma) make_plan_mfma(op, &gm);
   else if (takes_cols_path(op)) make_plan_cols(op, &gm);
   else make_plan(op, &gm);
   plan->col_tiles = gm.col_tiles;
@@ -372,7 +417,7 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   plan->csr_blocks = gm.csr_blocks;
   plan->topx_blocks = gm.topx_blocks;
   plan->grid_x = mfma ? gm.dense_blocks : gm.dense_block0 + gm.dense_blocks;  // (wide batches: the sparse terms are a launch of their own)
-  const int rows_per_pass = mfma ? 16 * sqllm::mfma_row_blocks(gm.batch) : sqllm::batch_tile(gm.batch);
+  const int rows_per_pass = wide ? (gm.batch > 0 ? gm.batch : 1) : mfma ? 16 * sqllm::mfma_row_blocks(gm.batch) : sqllm::batch_tile(gm.batch);
   plan->grid_y = (gm.batch + rows_per_pass - 1) / rows_per_pass;
   return SQLLM_OK;
 }
@@ -426,6 +471,48 @@ struct TransposedVec {
   }
   ~TransposedVec() {
     if (xT) (void)hipFreeAsync(xT, s);
+  }
+};
+
+// The wide matrix-core kernel takes vec split ONCE into bf16 planes (sqllm_mfma_split.hip: sqllm_split_vec).  Same kind
+// of scratch as TransposedVec: 6 bytes per element of vec (rows padded to 64) plus a zero block and the flag words;
+// without scratch the kernel splits in registers.
+constexpr int kSplitPlanesMinBatch = 64;
+struct SplitVec {
+  void* planes = nullptr;
+  uint32_t zero_chunk = 0;
+  uint32_t* flags = nullptr;
+  hipStream_t s = nullptr;
+  int acquire(const sqllm_op* ops, sqllm_stream_t stream, hipEvent_t* e0) {
+    s = static_cast<hipStream_t>(stream);
+    int from = knobs().split_planes_min_batch.load(std::memory_order_relaxed);
+    if (from == 0) from = kSplitPlanesMinBatch;
+    if (ops[0].batch < from || !ops[0].vec || ops[0].K <= 0) return SQLLM_OK;
+    const uint64_t chunks = sqllm::split_planes_chunks(ops[0].batch, ops[0].K);
+    if (chunks >= (1ull << 31)) return SQLLM_OK;  // 32-bit chunk numbers in the kernel
+    if (!knobs().scratch_in_capture.load(std::memory_order_relaxed)) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (!(hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone)) {
+        (void)hipGetLastError();
+        return SQLLM_OK;
+      }
+    }
+    keep_scratch_in_pool();
+    void* p = nullptr;
+    if (hipMallocAsync(&p, chunks * 16 + sqllm::kSplitFlagWgs * sizeof(uint32_t), s) != hipSuccess || !p) {
+      (void)hipGetLastError();  // no scratch: split in registers
+      return SQLLM_OK;
+    }
+    planes = p;
+    zero_chunk = (uint32_t)sqllm::split_planes_zero_chunk(ops[0].batch, ops[0].K);
+    flags = reinterpret_cast<uint32_t*>(static_cast<char*>(p) + chunks * 16);
+    const hipError_t e = sqllm::split_vec(ops[0].vec, planes, zero_chunk, flags, ops[0].batch, ops[0].K, s, e0 ? *e0 : nullptr);
+    if (e != hipSuccess) return static_cast<int>(e);  // (the destructor frees)
+    if (e0) *e0 = nullptr;  // (a profiled group starts with its split)
+    return SQLLM_OK;
+  }
+  ~SplitVec() {
+    if (planes) (void)hipFreeAsync(planes, s);
   }
 };
 
@@ -514,6 +601,13 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       const int rc = tv.acquire(ops, n, stream, &e0);
       if (rc != SQLLM_OK) return rc;
     }
+    SplitVec sv;
+    if (mfma && takes_wide_path(&ops[0])) {
+      int rc = validate(&ops[0]);  // (the split kernel reads vec by K: shape errors first)
+      if (rc != SQLLM_OK) return rc;
+      rc = sv.acquire(ops, stream, &e0);
+      if (rc != SQLLM_OK) return rc;
+    }
     float* const xT = tv.xT;
     const int Bp = tv.Bp;
     for (int i = 0; i < n; ++i) {
@@ -530,6 +624,9 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       a.x = op->vec;
       a.xT = (op->nnz > 0 && op->rows && op->cols && op->vals) ? xT : nullptr;
       a.Bp = Bp;
+      a.planes = sv.planes;
+      a.plane_zero_chunk = sv.zero_chunk;
+      a.plane_flags = sv.flags;
       a.ga.n_seg = 1;
       memset(a.ga.seg, 0, sizeof(a.ga.seg));
       sqllm::Segment& sg = a.ga.seg[0];
@@ -541,7 +638,9 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       sg.vals = op->vals;
       sg.full_rows = op->topX > 0 ? op->full_rows : nullptr;
       sg.full_idx = op->topX > 0 ? op->full_row_indices : nullptr;
-      if (mfma) make_plan_mfma(op, &sg.gm);
+      a.wide = mfma && takes_wide_path(op);
+      if (a.wide) a.wide_full_units = make_plan_wide(op, &sg.gm);
+      else if (mfma) make_plan_mfma(op, &sg.gm);
       else make_plan_cols(op, &sg.gm);
       a.ga.block0[0] = 0;
       for (int j = 1; j <= sqllm::kMaxSegments; ++j) a.ga.block0[j] = sg.gm.dense_block0 + sg.gm.dense_blocks;

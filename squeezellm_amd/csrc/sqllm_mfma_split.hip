@@ -30,6 +30,14 @@
 // the 8 elements of its B fragment, and x[row c][8 (r0 + kq) + s] as its A fragment: both sides enumerate the k's
 // of a matrix instruction the same way, which is all it needs (no cross-lane traffic; cf. dense_role_mfma).
 // Work decomposition, prefetch ping-pong, LDS meeting of the waves and the epilogue are the fp32 kernel's.
+//
+// The WIDE form (64 rows and more, sqllm_fused_wide below) takes vec split ONCE, by its own kernel (sqllm_split_vec), into
+// bf16 planes in stream-ordered scratch, laid out in FRAGMENT order: a 1-KB block per (16 rows, 32 k's, plane) holds the
+// 64 lanes' 16-byte A fragments back to back, blocks ordered [row block][k block][plane hi, mid, lo] -- a wave's load is
+// 1 KB contiguous, and no value is split more than once (in the kernels above: once per 64-column tile).  The split
+// kernel also reports whether any `lo` part is non-zero; where none is (vec came from fp16 values, as in
+// QuantLinearLUT.forward: 11 significant bits fit hi + mid) the lo plane is neither read nor multiplied (five partial
+// products instead of six).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -102,11 +110,110 @@ __device__ __forceinline__ bf16x8 as_frag(const uint32_t (&r)[4]) {
   return __builtin_bit_cast(bf16x8, u32x4v{r[0], r[1], r[2], r[3]});
 }
 
+// One phase of a wave's group: the 8 k's of each lane row (phase PH of its unit) against all MB row blocks.
+//   t        the lane's packed words of the unit (4 columns x R rows)
+//   dx       the phase's vec values: XMODE 0 fp32 (two registers per row block, split here), 2 / 3 ready-made planes
+//   lane_off byte offset of this lane's slot inside an entry row, plus the table's base (3-bit: all of it; 4-bit: bits
+//            16.. of it in byte 1 -- the low 16 bits of a 4-bit table's base arrive through `wmask`, OR-ed into the index
+//            bytes: bases are multiples of 16 KB, an index is < 16)
+template <int BITS, int MB, int XMODE, int PH>
+__device__ __forceinline__ void split_phase(const u32x4 (&t)[Fmt<BITS>::kRows], const u32x4 (&dx)[XMODE == 0 ? 2 * MB : XMODE * MB],
+                                            bool live, uint32_t lane_off, uint32_t wmask, f32x4 (&acc)[MB][4]) {
+  // A fragments of every row block
+  uint32_t ah[MB][4], am[MB][4], al[MB][4];
+  if constexpr (XMODE == 0) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const f32x4 lo4 = __builtin_bit_cast(f32x4, dx[2 * mb]), hi4 = __builtin_bit_cast(f32x4, dx[2 * mb + 1]);
+      float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = live ? v[i] : 0.f;
+      split8(v, ah[mb], am[mb], al[mb]);
+    }
+  } else {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const u32x4 h4 = dx[XMODE * mb], m4 = dx[XMODE * mb + 1], l4 = dx[XMODE * mb + XMODE - 1];
+      ah[mb][0] = h4.x; ah[mb][1] = h4.y; ah[mb][2] = h4.z; ah[mb][3] = h4.w;
+      am[mb][0] = m4.x; am[mb][1] = m4.y; am[mb][2] = m4.z; am[mb][3] = m4.w;
+      al[mb][0] = l4.x; al[mb][1] = l4.y; al[mb][2] = l4.z; al[mb][3] = l4.w;  // (XMODE 2: not used)
+    }
+  }
+  uint32_t t0[4], t1[4], t2[4];
+  if constexpr (BITS == 4) {
+    t0[0] = t[0].x; t0[1] = t[0].y; t0[2] = t[0].z; t0[3] = t[0].w;
+  } else {
+    t0[0] = t[0].x; t0[1] = t[0].y; t0[2] = t[0].z; t0[3] = t[0].w;
+    t1[0] = t[1].x; t1[1] = t[1].y; t1[2] = t[1].z; t1[3] = t[1].w;
+    t2[0] = t[2].x; t2[1] = t[2].y; t2[2] = t[2].z; t2[3] = t[2].w;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    // the 8 weights of column 4c + j: one ds_read_b64 each
+    u32x2 e[8];
+    if constexpr (BITS == 4) {
+      const uint32_t lo = (t0[j] & 0x0F0F0F0Fu) | wmask, hi = ((t0[j] >> 4) & 0x0F0F0F0Fu) | wmask;
+      const int off = j * 4096;
+      e[0] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C010400u) + off);
+      e[1] = lds_read_u32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C010400u) + off);
+      e[2] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C010500u) + off);
+      e[3] = lds_read_u32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C010500u) + off);
+      e[4] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C010600u) + off);
+      e[5] = lds_read_u32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C010600u) + off);
+      e[6] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C010700u) + off);
+      e[7] = lds_read_u32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C010700u) + off);
+    } else {
+      const uint32_t tbj = j * 2048 + lane_off;
+      e[0] = lds_read_u32x2(tbj | field3_x256<8 * PH + 0>(t0[j], t1[j], t2[j]));
+      e[1] = lds_read_u32x2(tbj | field3_x256<8 * PH + 1>(t0[j], t1[j], t2[j]));
+      e[2] = lds_read_u32x2(tbj | field3_x256<8 * PH + 2>(t0[j], t1[j], t2[j]));
+      e[3] = lds_read_u32x2(tbj | field3_x256<8 * PH + 3>(t0[j], t1[j], t2[j]));
+      e[4] = lds_read_u32x2(tbj | field3_x256<8 * PH + 4>(t0[j], t1[j], t2[j]));
+      e[5] = lds_read_u32x2(tbj | field3_x256<8 * PH + 5>(t0[j], t1[j], t2[j]));
+      e[6] = lds_read_u32x2(tbj | field3_x256<8 * PH + 6>(t0[j], t1[j], t2[j]));
+      e[7] = lds_read_u32x2(tbj | field3_x256<8 * PH + 7>(t0[j], t1[j], t2[j]));
+    }
+    uint32_t bh[4], bm[4], bl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bh[i] = __builtin_amdgcn_perm(e[2 * i + 1].x, e[2 * i].x, 0x05040100u);  // the low halves: hi parts
+      bm[i] = __builtin_amdgcn_perm(e[2 * i + 1].x, e[2 * i].x, 0x07060302u);  // the high halves: mid parts
+      bl[i] = __builtin_amdgcn_perm(e[2 * i + 1].y, e[2 * i].y, 0x05040100u);
+    }
+    const bf16x8 Bh = as_frag(bh), Bm = as_frag(bm), Bl = as_frag(bl);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const bf16x8 Ah = as_frag(ah[mb]), Am = as_frag(am[mb]), Al = as_frag(al[mb]);
+      f32x4 c = acc[mb][j];
+      // small partial products first
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, c, 0, 0, 0);
+      if constexpr (XMODE != 2) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, c, 0, 0, 0);
+      acc[mb][j] = c;
+    }
+  }
+}
+
+// exact split of one codebook value into its LDS entry {hi | mid << 16, lo}
+__device__ __forceinline__ u32x2 split_entry(float v) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, v);
+  const uint32_t hb = b & 0xFFFF0000u;
+  const float r1 = v - __builtin_bit_cast(float, hb);
+  const uint32_t mbits = __builtin_bit_cast(uint32_t, r1) & 0xFFFF0000u;
+  const float r2 = r1 - __builtin_bit_cast(float, mbits);
+  return u32x2{(hb >> 16) | mbits, __builtin_bit_cast(uint32_t, r2) >> 16};
+}
+
 template <int BITS, int MB, int WAVES>
 __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ x, const u32x4* __restrict__ q,
                                                       float* __restrict__ y, const float* __restrict__ lut, int K, int N,
                                                       int batch, int m0, int bid, int n_col_tiles, int units_total,
                                                       int units_per_wg, int units_stride, float* lds) {
+  constexpr int XMODE = 0;  // vec = fp32 rows, split in registers
+  constexpr int NX = 2 * MB;  // 16-byte registers of one phase's vec values
   using F = Fmt<BITS>;
   constexpr int L = F::kLut, R = F::kRows, KU = F::kK;
   constexpr int NPH = KU / 8;  // phases of 8 k's per unit (4-bit: 1, 3-bit: 4)
@@ -176,17 +283,17 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < R; ++r) dw[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(qbase + (off + r * row_bytes)));
   };
-  auto load_x = [&](int g, int ph, f32x4 (&dx)[2 * MB]) {
+  auto load_x = [&](int g, int ph, u32x4 (&dx)[NX]) {
     const int u = clamp_unit(group_unit(g));
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       const float* p = x + xrow[mb] + u * KU + 8 * ph;
-      dx[2 * mb] = *reinterpret_cast<const f32x4*>(p);
-      dx[2 * mb + 1] = *reinterpret_cast<const f32x4*>(p + 4);
+      dx[2 * mb] = *reinterpret_cast<const u32x4*>(p);
+      dx[2 * mb + 1] = *reinterpret_cast<const u32x4*>(p + 4);
     }
   };
   u32x4 wa[R], wb[R];
-  f32x4 xa[2 * MB], xb[2 * MB];
+  u32x4 xa[NX], xb[NX];
   load_w(0, wa);
   load_x(0, 0, xa);
   asm volatile("" ::: "memory");
@@ -196,12 +303,7 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
     char* base = reinterpret_cast<char*>(lds);
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
-      const uint32_t b = __builtin_bit_cast(uint32_t, ev[i]);
-      const uint32_t hb = b & 0xFFFF0000u;
-      const float r1 = ev[i] - __builtin_bit_cast(float, hb);
-      const uint32_t mbits = __builtin_bit_cast(uint32_t, r1) & 0xFFFF0000u;
-      const float r2 = r1 - __builtin_bit_cast(float, mbits);
-      *reinterpret_cast<u32x2*>(base + 8 * (tid + T * i)) = u32x2{(hb >> 16) | mbits, __builtin_bit_cast(uint32_t, r2) >> 16};
+      *reinterpret_cast<u32x2*>(base + 8 * (tid + T * i)) = split_entry(ev[i]);
     }
   }
   f32x4 acc[MB][4];
@@ -211,91 +313,23 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
     for (int j = 0; j < 4; ++j) acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();  // codebooks staged (and everybody has left the previous piece's slabs)
 
-  // one phase: the 8 k's of each lane row (phase PH of its unit) against all MB row blocks
-  auto phase = [&](const u32x4 (&t)[R], auto ph_tag, const f32x4 (&dx)[2 * MB], int g) {
-    constexpr int PH = decltype(ph_tag)::value;
-    const bool live = group_unit(g) < u_end;
-    // A fragments of every row block
-    uint32_t ah[MB][4], am[MB][4], al[MB][4];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const f32x4 lo4 = dx[2 * mb], hi4 = dx[2 * mb + 1];
-      float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = live ? v[i] : 0.f;
-      split8(v, ah[mb], am[mb], al[mb]);
-    }
-    uint32_t t0[4], t1[4], t2[4];
-    if constexpr (BITS == 4) {
-      t0[0] = t[0].x; t0[1] = t[0].y; t0[2] = t[0].z; t0[3] = t[0].w;
-    } else {
-      t0[0] = t[0].x; t0[1] = t[0].y; t0[2] = t[0].z; t0[3] = t[0].w;
-      t1[0] = t[1].x; t1[1] = t[1].y; t1[2] = t[1].z; t1[3] = t[1].w;
-      t2[0] = t[2].x; t2[1] = t[2].y; t2[2] = t[2].z; t2[3] = t[2].w;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // the 8 weights of column 4c + j: one ds_read_b64 each
-      u32x2 e[8];
-      if constexpr (BITS == 4) {
-        const uint32_t lo = t0[j] & 0x0F0F0F0Fu, hi = (t0[j] >> 4) & 0x0F0F0F0Fu;
-        const int off = j * 4096;
-        e[0] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0400u) + off);
-        e[1] = lds_read_u32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0400u) + off);
-        e[2] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0500u) + off);
-        e[3] = lds_read_u32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0500u) + off);
-        e[4] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0600u) + off);
-        e[5] = lds_read_u32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0600u) + off);
-        e[6] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C0C0700u) + off);
-        e[7] = lds_read_u32x2(__builtin_amdgcn_perm(hi, lane_off, 0x0C0C0700u) + off);
-      } else {
-        const uint32_t tbj = j * 2048 + lane_off;
-        e[0] = lds_read_u32x2(tbj | field3_x256<8 * PH + 0>(t0[j], t1[j], t2[j]));
-        e[1] = lds_read_u32x2(tbj | field3_x256<8 * PH + 1>(t0[j], t1[j], t2[j]));
-        e[2] = lds_read_u32x2(tbj | field3_x256<8 * PH + 2>(t0[j], t1[j], t2[j]));
-        e[3] = lds_read_u32x2(tbj | field3_x256<8 * PH + 3>(t0[j], t1[j], t2[j]));
-        e[4] = lds_read_u32x2(tbj | field3_x256<8 * PH + 4>(t0[j], t1[j], t2[j]));
-        e[5] = lds_read_u32x2(tbj | field3_x256<8 * PH + 5>(t0[j], t1[j], t2[j]));
-        e[6] = lds_read_u32x2(tbj | field3_x256<8 * PH + 6>(t0[j], t1[j], t2[j]));
-        e[7] = lds_read_u32x2(tbj | field3_x256<8 * PH + 7>(t0[j], t1[j], t2[j]));
-      }
-      uint32_t bh[4], bm[4], bl[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bh[i] = __builtin_amdgcn_perm(e[2 * i + 1].x, e[2 * i].x, 0x05040100u);  // the low halves: hi parts
-        bm[i] = __builtin_amdgcn_perm(e[2 * i + 1].x, e[2 * i].x, 0x07060302u);  // the high halves: mid parts
-        bl[i] = __builtin_amdgcn_perm(e[2 * i + 1].y, e[2 * i].y, 0x05040100u);
-      }
-      const bf16x8 Bh = as_frag(bh), Bm = as_frag(bm), Bl = as_frag(bl);
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const bf16x8 Ah = as_frag(ah[mb]), Am = as_frag(am[mb]), Al = as_frag(al[mb]);
-        f32x4 c = acc[mb][j];
-        // small partial products first
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, c, 0, 0, 0);
-        acc[mb][j] = c;
-      }
-    }
+  auto phase = [&](const u32x4 (&t)[R], auto ph_tag, const u32x4 (&dx)[NX], int g) {
+    split_phase<BITS, MB, XMODE, decltype(ph_tag)::value>(t, dx, group_unit(g) < u_end, lane_off, 0u, acc);
   };
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
   using P2 = std::integral_constant<int, 2>;
   using P3 = std::integral_constant<int, 3>;
-  // decode group g out of (w, xcur = its phase-0 vec values); later phases' values are loaded one phase ahead,
-  // the NEXT group's weights and phase-0 values (into wn / xn) before the first phase
-  auto decode_group = [&](int g, const u32x4 (&w)[R], f32x4 (&xcur)[2 * MB], u32x4 (&wn)[R], f32x4 (&xn)[2 * MB]) {
+  // decode group g out of (w, xcur = its phase-0 vec values); the NEXT group's weights (into wn) are loaded before the
+  // first phase, its phase-0 values (into xn) before the last.  With four phases the values of phase p + 1 are loaded
+  // while phase p runs, alternating between xcur and xo -- the next group's phase 0 lands in xcur again (xn == xcur).
+  auto decode_group = [&](int g, const u32x4 (&w)[R], u32x4 (&xcur)[NX], u32x4 (&wn)[R], u32x4 (&xn)[NX], u32x4 (&xo)[NX]) {
     load_w(g + 1, wn);
     if constexpr (NPH == 1) {
       load_x(g + 1, 0, xn);
       __builtin_amdgcn_sched_barrier(0);
       phase(w, P0{}, xcur, g);
     } else {
-      f32x4 xo[2 * MB];
       load_x(g, 1, xo);
       __builtin_amdgcn_sched_barrier(0);
       phase(w, P0{}, xcur, g);
@@ -312,8 +346,13 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
     __builtin_amdgcn_sched_barrier(0);
   };
   for (int g = 0; g < n_g; g += 2) {
-    decode_group(g, wa, xa, wb, xb);
-    decode_group(g + 1, wb, xb, wa, xa);
+    if constexpr (NPH == 1) {
+      decode_group(g, wa, xa, wb, xb, xb);
+      decode_group(g + 1, wb, xb, wa, xa, xa);
+    } else {
+      decode_group(g, wa, xa, wb, xa, xb);
+      decode_group(g + 1, wb, xa, wa, xa, xb);
+    }
   }
 
   // ---- waves meet in LDS, one row block at a time (see dense_role_mfma) ----
@@ -339,6 +378,204 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
   }  // pieces
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 64 rows and more: the WIDE form.  The kernels above give a workgroup ONE 64-column tile and divide its k's between
+// the eight waves: every wave reads different vec values, nothing a wave loads is of use to another, and at 2048
+// rows the 64 x K values of a row block are fetched once per column tile -- 9 GB per 13B gate/up op, with 9 % of it
+// found in the L2 (profiles/r04_split_planes_pmc.txt: 32 workgroups per XCD on 32 different row blocks), i.e. a kernel
+// bound by the fabric at 5.8 TB/s with the matrix pipe 43 % busy.  Here a workgroup takes EIGHT column tiles -- one
+// per wave, codebook table private to the wave, 16 KB (4-bit) / 8 KB (3-bit) of LDS each -- and every wave walks the
+// SAME k's: the A fragments of a step are fetched from the L2 once per workgroup and found in the CU's vector cache by
+// the other seven waves (eight times less vec traffic), no cross-wave sum, no barrier anywhere in the kernel; a wave
+// adds its 64 x 64 results straight to mul.  Grid: x = (group of 8 column tiles, K slice), y = block of 64 rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWideTiles = 8;  // column tiles per workgroup = waves
+
+template <int BITS, int XMODE>
+__device__ __forceinline__ void dense_role_mfma_wide(const void* __restrict__ xv, uint32_t zero_chunk, const u32x4* __restrict__ q,
+                                                     float* __restrict__ y, const float* __restrict__ lut, int K, int N, int batch,
+                                                     int m0, int ct, int u_beg, int u_end, bool atomic) {
+  using F = Fmt<BITS>;
+  constexpr int MB = 4;
+  constexpr int L = F::kLut, R = F::kRows, KU = F::kK;
+  constexpr int NPH = KU / 8;
+  constexpr int NX = XMODE == 0 ? 2 * MB : XMODE * MB;
+  constexpr int kCbBytes = split_codebook_bytes(BITS);
+  const float* x = static_cast<const float*>(xv);
+  const u32x4* xc = static_cast<const u32x4*>(xv);  // (planes: 16-byte chunks)
+  __builtin_amdgcn_s_waitcnt(0);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, grp = lane >> 4;
+  const int row_stride = N / 4;  // in 16-byte units
+  const char* qbase = reinterpret_cast<const char*>(q);
+  const uint32_t row_bytes = 16u * (uint32_t)row_stride;
+  int xrow[MB];        // fp32 vec: this lane's batch rows (rows past the batch re-read its last row; never stored)
+  uint32_t xblk[MB];   // planes: first chunk of the row block's k block 0
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    int r = m0 + 16 * mb + i16;
+    if (r > batch - 1) r = batch - 1;
+    xrow[mb] = r * K;
+    xblk[mb] = (uint32_t)(m0 / 16 + mb) * (uint32_t)(K / 32) * 192u;
+  }
+  const int col0 = ct * kTileN;
+  const uint32_t wbase = (uint32_t)wave * (uint32_t)kCbBytes;  // this wave's table
+  const uint32_t slot = 8 * (i16 + 16 * (grp & 1));
+  // (see split_phase: a 4-bit table base is 16 KB * wave -- bits 14, 15 ride in the index bytes, bit 16 in byte 1 of lane_off)
+  const uint32_t lane_off = BITS == 4 ? (slot | ((wbase >> 16) << 8)) : (wbase + slot);
+  const uint32_t wmask = BITS == 4 ? 0x01010101u * ((wbase >> 8) & 0xC0u) : 0u;
+
+  // ---- this wave's codebook values: entry e = lane + 64 i of the tile's 4 * L * 32 eight-byte entries ----
+  constexpr int NST = 4 * L * 32 / 64;
+  float ev[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int e = lane + 64 * i;
+    const int row = e >> 5, sl = e & 31;
+    int c = col0 + 4 * (sl & 15) + row / L;
+    if (c > N - 1) c = N - 1;
+    ev[i] = lut[(size_t)c * L + (row % L)];
+  }
+  const int n_g = (u_end - u_beg + 3) / 4;
+  int cidx = col0 / 4 + i16;
+  if (cidx > row_stride - 1) cidx = row_stride - 1;
+  const uint32_t lane_bytes = 16u * (uint32_t)cidx;
+  auto group_unit = [&](int g) { return u_beg + 4 * g + grp; };
+  auto clamp_unit = [&](int u) {
+    if (u > u_end - 1) u = u_end - 1;
+    return u;
+  };
+  auto load_w = [&](int g, u32x4 (&dw)[R]) {
+    const int u = clamp_unit(group_unit(g));
+    const uint32_t off = (uint32_t)(u * R) * row_bytes + lane_bytes;
+#pragma unroll
+    for (int r = 0; r < R; ++r) dw[r] = *reinterpret_cast<const u32x4*>(qbase + (off + r * row_bytes));  // (re-read by every row block: cached)
+  };
+  auto load_x = [&](int g, int ph, u32x4 (&dx)[NX]) {
+    const int gu = group_unit(g);
+    const int u = clamp_unit(gu);
+    if constexpr (XMODE == 0) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const float* p = x + xrow[mb] + u * KU + 8 * ph;
+        dx[2 * mb] = *reinterpret_cast<const u32x4*>(p);
+        dx[2 * mb + 1] = *reinterpret_cast<const u32x4*>(p + 4);
+      }
+    } else {
+      // fragment order (sqllm_split_vec): 4-bit -- the group's 32 k's are ONE k block, lane for lane; 3-bit -- a lane
+      // row's unit is a k block of its own, phase ph = its quarter
+      const bool live = gu < u_end;
+      const uint32_t kb = BITS == 4 ? (uint32_t)u >> 2 : (uint32_t)u;
+      const uint32_t lp = BITS == 4 ? (uint32_t)lane : (uint32_t)(16 * ph + i16);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const uint32_t c = live ? xblk[mb] + 192u * kb + lp : zero_chunk + lp;
+#pragma unroll
+        for (int pl = 0; pl < XMODE; ++pl) dx[XMODE * mb + pl] = xc[c + 64u * pl];
+      }
+    }
+  };
+  // weights two groups ahead (they come from HBM / the Infinity Cache), vec values one phase ahead (L2 / vector cache)
+  u32x4 wa[R], wb[R];
+  u32x4 xa[NX], xb[NX];
+  load_w(0, wa);
+  load_w(1, wb);
+  load_x(0, 0, xa);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    char __attribute__((address_space(3)))* base = reinterpret_cast<char __attribute__((address_space(3)))*>(wbase);
+#pragma unroll
+    for (int i = 0; i < NST; ++i) *reinterpret_cast<u32x2 __attribute__((address_space(3)))*>(base + 8 * (lane + 64 * i)) = split_entry(ev[i]);
+  }
+  f32x4 acc[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the table is this wave's own: LDS operations of one wave complete in order, no barrier
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  using P3 = std::integral_constant<int, 3>;
+  auto phase = [&](const u32x4 (&t)[R], auto ph_tag, const u32x4 (&dx)[NX], int g) {
+    split_phase<BITS, MB, XMODE, decltype(ph_tag)::value>(t, dx, group_unit(g) < u_end, lane_off, wmask, acc);
+  };
+  // group g out of (w = its words, xcur = its phase-0 values); w is refilled with group g + 2's words once a copy is taken.
+  // Loads return in order: the vec loads of the next phase go out BEFORE the far-ahead weight load, so that waiting for
+  // them does not mean waiting for it.
+  auto decode_group = [&](int g, u32x4 (&w)[R], u32x4 (&xcur)[NX], u32x4 (&xn)[NX], u32x4 (&xo)[NX]) {
+    u32x4 t[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) t[r] = w[r];
+    if constexpr (NPH == 1) {
+      load_x(g + 1, 0, xn);
+      load_w(g + 2, w);
+      __builtin_amdgcn_sched_barrier(0);
+      phase(t, P0{}, xcur, g);
+    } else {
+      load_x(g, 1, xo);
+      load_w(g + 2, w);
+      __builtin_amdgcn_sched_barrier(0);
+      phase(t, P0{}, xcur, g);
+      load_x(g, 2, xcur);
+      __builtin_amdgcn_sched_barrier(0);
+      phase(t, P1{}, xo, g);
+      load_x(g, 3, xo);
+      __builtin_amdgcn_sched_barrier(0);
+      phase(t, P2{}, xcur, g);
+      load_x(g + 1, 0, xn);
+      __builtin_amdgcn_sched_barrier(0);
+      phase(t, P3{}, xo, g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int g = 0; g < n_g; g += 2) {
+    if constexpr (NPH == 1) {
+      decode_group(g, wa, xa, xb, xb);
+      decode_group(g + 1, wb, xb, xa, xa);
+    } else {
+      decode_group(g, wa, xa, xa, xb);
+      decode_group(g + 1, wb, xa, xa, xb);
+    }
+  }
+  // ---- results: lane (i16, grp) holds rows 16 mb + 4 grp + {x, y, z, w} of columns 4 i16 + j.  A workgroup that covered
+  // all of K owns its outputs (the launch's other workgroups write other tiles, the sparse terms were an earlier launch):
+  // 16-byte read-add-write; K slices add atomically -- the L2 takes ~1.2 fp32 atomics per clock and channel, 57 M of them
+  // (13B gate/up, 2048 rows, two slices) were 177 us of a 1.39-ms kernel (profiles/r04_wide_ablate.txt).
+  const int c0 = col0 + 4 * i16;
+  if (c0 < N) {  // (N is a multiple of 4: the lane's four columns exist together)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int r0 = m0 + 16 * mb + 4 * grp;
+      float* p = y + (size_t)r0 * N + c0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (r0 + e < batch) {
+          float* pe = p + (size_t)e * N;
+          const f32x4 v = {acc[mb][0][e], acc[mb][1][e], acc[mb][2][e], acc[mb][3][e]};
+          if (atomic) {
+            acc_add(pe + 0, v.x);
+            acc_add(pe + 1, v.y);
+            acc_add(pe + 2, v.z);
+            acc_add(pe + 3, v.w);
+          } else {
+            f32x4 o = *reinterpret_cast<const f32x4*>(pe);
+            o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+            *reinterpret_cast<f32x4*>(pe) = o;
+          }
+        }
+      }
+    }
+  }
+}
 }  // namespace
 
 template <int BITS, int MB, int WAVES>
@@ -354,6 +591,83 @@ sqllm_fused_batched_split(const float* x, const GroupArgs ga) {
                                          (int)blockIdx.x, gm.col_tiles, gm.units_total, gm.units_per_wg,
                                          gm.dense_blocks == gm.col_tiles * gm.k_slices ? gm.k_slices * gm.units_per_wg : gm.units_total,
                                          lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// vec split once into bf16 planes in fragment order (see the header).  Chunk = 16 bytes = 8 k's of one row; chunk index
+//   ((rb * (K / 32) + kb) * 3 + plane) * 64 + lane,   lane = 16 * ((k / 8) % 4) + row % 16,  rb = row / 16, kb = k / 32,
+// rows padded with zeros to a multiple of 64, and one all-zero (rb, kb) triple of blocks at the very end (`zero_chunk`:
+// where lanes past the end of a K range read).  flags[w] = 1 if workgroup w met a non-zero lo part; the grid is always
+// kSplitFlagWgs workgroups, so the consumer ORs a fixed number of flags and nothing needs zeroing beforehand.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sqllm_split_vec(const float* __restrict__ x, u32x4* __restrict__ planes, uint32_t zero_chunk,
+                                                       uint32_t* __restrict__ flags, int batch, int K) {
+  const uint32_t KB = (uint32_t)K / 32;
+  const uint32_t n_frag = zero_chunk / 3 + 64;  // (rb, kb, lane) triples, the zero triple included
+  uint32_t any = 0;
+  for (uint32_t f = blockIdx.x * 256 + threadIdx.x; f < n_frag; f += kSplitFlagWgs * 256) {
+    const uint32_t lane = f & 63, blk = f >> 6;  // blk = rb * KB + kb
+    const uint32_t rb = blk / KB, kb = blk - rb * KB;
+    const uint32_t row = 16 * rb + (lane & 15), k = 32 * kb + 8 * (lane >> 4);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (row < (uint32_t)batch && 192 * blk < zero_chunk) {
+      const float* p = x + (size_t)row * K + k;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    uint32_t h[4], m[4], l[4];
+    split8(v, h, m, l);
+    u32x4* o = planes + ((size_t)blk * 192 + lane);
+    o[0] = u32x4{h[0], h[1], h[2], h[3]};
+    o[64] = u32x4{m[0], m[1], m[2], m[3]};
+    o[128] = u32x4{l[0], l[1], l[2], l[3]};
+    any |= l[0] | l[1] | l[2] | l[3];
+  }
+  // (a lo part is 0 or a non-zero bf16 -- never -0: the differences above are exact, x - x = +0)
+  const int wg_any = __syncthreads_or(any != 0);
+  if (threadIdx.x == 0) flags[blockIdx.x] = wg_any ? 1u : 0u;
+}
+
+// wide form (dense_role_mfma_wide): XP = vec as bf16 planes (with the lo flags) or as fp32 rows (no scratch: split in registers).
+// 1-D grid over UNITS = (64-row block rb, group of 8 column tiles cg), unit = rb * col_groups + cg: workgroups
+// [0, full_units) take one unit each over all of K; the remaining units -- the last, partial round of one workgroup per
+// CU -- are cut into gm.k_slices K slices of gm.units_per_wg units, one workgroup each (make_plan_wide).
+template <int BITS, bool XP>
+__global__ void __launch_bounds__(kWaves * 64, 2)
+sqllm_fused_wide(const void* xv, uint32_t zero_chunk, const uint32_t* flags, int full_units, const GroupArgs ga) {
+  __shared__ __attribute__((aligned(16))) char lds[kWideTiles * split_codebook_bytes(BITS)];
+  static_assert(kWaves == kWideTiles, "one column tile per wave");
+  const Segment sg = ga.seg[0];
+  asm volatile("" ::SQLLM_SEG_OPERANDS(sg), "s"(xv), "s"(flags), "s"(full_units));
+  __builtin_amdgcn_sched_barrier(0);
+  const KernelGeom& gm = sg.gm;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  int unit = blockIdx.x, u_beg = 0, u_end = gm.units_total;
+  const bool sliced = unit >= full_units && gm.k_slices > 1;
+  if (sliced) {
+    const int t = unit - full_units;
+    const int q = t / gm.k_slices;
+    unit = full_units + q;
+    u_beg = (t - q * gm.k_slices) * gm.units_per_wg;
+    if (u_end > u_beg + gm.units_per_wg) u_end = u_beg + gm.units_per_wg;
+  }
+  const int col_groups = (gm.col_tiles + kWideTiles - 1) / kWideTiles;
+  const int rb = unit / col_groups, cg = unit - rb * col_groups;
+  const int ct = cg * kWideTiles + wave;
+  asm volatile("" ::"v"(lds));  // (the role addresses the tables by number: keep the array)
+  if (ct >= gm.col_tiles || u_beg >= u_end) return;  // (no barrier below: a wave without work just leaves)
+  const int m0 = rb * 64;
+  const u32x4* q = reinterpret_cast<const u32x4*>(sg.q);
+  if constexpr (XP) {
+    static_assert(kSplitFlagWgs == 256, "four flags per lane");
+    const uint32_t f = flags[lane] | flags[lane + 64] | flags[lane + 128] | flags[lane + 192];
+    const bool has_lo = __builtin_amdgcn_ballot_w64(f != 0) != 0;
+    if (has_lo) dense_role_mfma_wide<BITS, 3>(xv, zero_chunk, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced);
+    else dense_role_mfma_wide<BITS, 2>(xv, zero_chunk, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced);
+  } else {
+    dense_role_mfma_wide<BITS, 0>(xv, 0, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -425,6 +739,24 @@ hipError_t launch_split_bits(const LaunchArgs& a, hipStream_t stream) {
   }
 }
 
+template <int BITS>
+hipError_t launch_wide_bits(const LaunchArgs& a, hipStream_t stream) {
+  const KernelGeom& gm = a.ga.seg[0].gm;
+  dim3 grid(gm.dense_blocks);
+  if (a.planes) {
+    auto kern = sqllm_fused_wide<BITS, true>;
+    if (a.ev_start || a.ev_stop)
+      hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, a.planes, a.plane_zero_chunk, a.plane_flags, a.wide_full_units, a.ga);
+    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.planes, a.plane_zero_chunk, a.plane_flags, a.wide_full_units, a.ga);
+  } else {
+    auto kern = sqllm_fused_wide<BITS, false>;
+    const uint32_t* none = nullptr;
+    if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, a.x, 0u, none, a.wide_full_units, a.ga);
+    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.x, 0u, none, a.wide_full_units, a.ga);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace
 
 // 1..kMaxSegments ops over one vec (a.ga), up to kSmallRows rows: all three terms of every op in one launch
@@ -444,8 +776,18 @@ hipError_t launch_small_split(int bits, const LaunchArgs& a, hipStream_t stream)
   return hipGetLastError();
 }
 
-// one op (a.ga.seg[0]), operator ABI, batch rows through the bf16 matrix cores with split operands (dense term only)
+// vec [batch, K] -> bf16 planes in fragment order + lo flags (sqllm_split_vec); `planes` holds split_planes_chunks(batch, K) chunks
+hipError_t split_vec(const float* x, void* planes, uint32_t zero_chunk, uint32_t* flags, int batch, int K, hipStream_t stream, hipEvent_t ev_start) {
+  u32x4* out = static_cast<u32x4*>(planes);
+  if (ev_start) hipExtLaunchKernelGGL(sqllm_split_vec, dim3(kSplitFlagWgs), dim3(256), 0, stream, ev_start, nullptr, 0, x, out, zero_chunk, flags, batch, K);
+  else hipLaunchKernelGGL(sqllm_split_vec, dim3(kSplitFlagWgs), dim3(256), 0, stream, x, out, zero_chunk, flags, batch, K);
+  return hipGetLastError();
+}
+
+// one op (a.ga.seg[0]), operator ABI, batch rows through the bf16 matrix cores with split operands (dense term only);
+// a.wide: the wide form, A operands ready-made from split_vec's planes (a.planes) or split in registers
 hipError_t launch_batched_mfma_split(int bits, const LaunchArgs& a, hipStream_t stream) {
+  if (a.wide) return bits == 4 ? launch_wide_bits<4>(a, stream) : launch_wide_bits<3>(a, stream);
   return bits == 4 ? launch_split_bits<4>(a, stream) : launch_split_bits<3>(a, stream);
 }
 

@@ -98,14 +98,22 @@ def test_plan_geometry():
     assert _lib.plan_query(3, 4096, 4096, batch=17)["grid_y"] == 1
     assert _lib.plan_query(4, 4096, 4096, batch=9)["grid_y"] == 1
     assert _lib.plan_query(4, 4096, 4096, batch=33)["grid_y"] == 1
-    assert _lib.plan_query(4, 4096, 4096, batch=2048)["grid_y"] == 32
+    assert _lib.plan_query(4, 4096, 4096, batch=511)["grid_y"] == 8
+    # from 512 rows the WIDE form: a 1-D grid over units of 64 rows x 8 column tiles, whole rounds of one unit per CU over
+    # all of K, the last partial round cut into K slices (csrc/sqllm_capi.hip: make_plan_wide)
+    pq = _lib.plan_query(4, 4096, 4096, batch=2048)  # 32 row blocks x 8 column groups = 256 units: exactly one round
+    assert pq["grid_y"] == 1 and pq["dense_blocks"] == 256 and pq["k_slices"] == 1
     pm = _lib.plan_query(4, 5120, 13824, batch=16)
     # ... whose dense work is the flattened (column tile, unit) space in equal ranges, one round of workgroups
     assert pm["groups_per_wave"] % 32 == 0 and pm["dense_blocks"] <= 512
     total = pm["col_tiles"] * (5120 // 8)
     assert pm["dense_blocks"] * pm["groups_per_wave"] >= total > (pm["dense_blocks"] - 1) * pm["groups_per_wave"]
-    pw = _lib.plan_query(4, 5120, 13824, batch=2048)  # 32 passes of 64 rows share the chip: 256 / 32 ranges
+    pw = _lib.plan_query(4, 5120, 13824, batch=2048)  # 32 x 27 = 864 units: 3 whole rounds + 96 units in two K slices of 320
+    assert pw["grid_y"] == 1 and pw["k_slices"] == 2 and pw["groups_per_wave"] == 320 and pw["dense_blocks"] == 768 + 2 * 96
+    _lib.set_option("mfma_wide_min_batch", 1 << 30)  # ... unless switched off: 32 passes of 64 rows share the chip, 256 / 32 ranges
+    pw = _lib.plan_query(4, 5120, 13824, batch=2048)
     assert pw["grid_y"] == 32 and pw["dense_blocks"] == 8
+    _lib.set_option("mfma_wide_min_batch", 0)
     _lib.set_option("mfma_min_batch", 1 << 30)  # ... unless switched off: batch tiles of 8
     assert _lib.plan_query(4, 4096, 4096, batch=9)["grid_y"] == 2
     _lib.set_option("mfma_min_batch", 0)
@@ -329,6 +337,13 @@ def test_range_plans_cover_every_unit_exactly_once():
                     U = K // (8 if bits == 4 else 32)
                     upw, blocks, tiles, ks = p["groups_per_wave"], p["dense_blocks"], p["col_tiles"], p["k_slices"]
                     assert upw >= 1 and blocks >= 1
+                    if batch >= 512:  # the wide form: units of 64 rows x 8 column tiles; whole rounds unsliced, the rest in ks slices
+                        units = -(-tiles // 8) * -(-batch // 64)
+                        full = units // 256 * 256
+                        assert blocks == full + (units - full) * ks and upw % 4 == 0, (bits, K, N, batch, p)
+                        assert ks * upw >= U > (ks - 1) * upw, (bits, K, N, batch, p)
+                        assert ks == 1 or (units - full) * ks <= 256, (bits, K, N, batch, p)  # the sliced tail fits one round
+                        continue
                     if blocks == tiles * ks:  # tile-aligned (or a contiguous cut that happens to be)
                         assert ks * upw >= U > (ks - 1) * upw, (bits, K, N, batch, p)
                         seen_aligned += 1

@@ -80,6 +80,64 @@ def test_ppl_eval_batch_2048(qc, gpu, bits):
     assert H.rel_err(got, H.oracle_ref(case, x, mul, "hybrid")) <= TOL_FP64
 
 
+@pytest.mark.parametrize("vec", ["fp16-born", "fp32"])
+@pytest.mark.parametrize("planes", [True, False], ids=["planes", "in-register-split"])
+@pytest.mark.parametrize("bits,K,N", [(4, 1024, 1092), (3, 1024, 776), (4, 4160, 516), (3, 2080, 1028), (4, 32, 4), (3, 32, 8)])
+@pytest.mark.parametrize("batch", [17, 64, 130, 700])
+def test_wide_form_vs_oracle(qc, gpu, vec, planes, bits, K, N, batch):
+    """The wide form of the split matrix-core kernel (csrc/sqllm_mfma_split.hip: sqllm_fused_wide; default from 512 rows),
+    forced from 17 rows up: workgroups of eight column tiles, vec from bf16 planes in fragment order (sqllm_split_vec) or --
+    without scratch -- split in registers; fp16-born vec takes the five-product path (no lo plane), fp32 vec all six.
+    Shapes: a last column group of one tile and 4 columns (1092), K that is not a whole number of 32-k steps times
+    anything convenient (4160 = 130 x 32), a single unit, row blocks with 1..64 live rows.  On the 256-CU part the units
+    (64 rows x 8 column tiles) of these shapes fit one round, so every workgroup is a K slice that adds atomically;
+    test_wide_form_whole_rounds covers the read-add-write epilogue of unsliced units."""
+    import torch
+
+    from squeezellm_amd import _lib
+
+    case = H.make_case(bits, K, N, sparse=0.02, topX=3, heavy_rows=1 if N >= 8 else 0, seed=bits * 7 + K + N + batch)
+    rng = np.random.default_rng(batch)
+    x = rng.normal(size=(batch, K)).astype(np.float32)
+    if vec == "fp16-born":
+        x = x.astype(np.float16).astype(np.float32)
+    mul = rng.normal(0, 0.5, size=(batch, N)).astype(np.float32)
+    t = H.to_torch(case, gpu)
+    yt = torch.from_numpy(mul).to(gpu)
+    try:
+        _lib.set_option("mfma_wide_min_batch", 17)
+        _lib.set_option("split_planes_min_batch", 1 if planes else 1 << 30)
+        H.call_op(qc, t, torch.from_numpy(x).to(gpu), yt, "hybrid", True)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_option("mfma_wide_min_batch", 0)
+        _lib.set_option("split_planes_min_batch", 0)
+    assert H.rel_err(yt.cpu().numpy(), H.oracle_ref(case, x, mul, "hybrid")) <= TOL_FP64
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("cus", [8, 24])
+def test_wide_form_whole_rounds(qc, gpu, bits, cus):
+    """Planned for a part of 8 / 24 CUs (option cu_count), 3 row blocks x 9 column groups = 27 units make whole rounds of
+    unsliced units (16-byte read-add-write into mul, which starts non-zero) plus a sliced, atomically adding tail."""
+    import torch
+
+    from squeezellm_amd import _lib
+
+    K, N, batch = 2048, 4608 - 60, 150
+    case = H.make_case(bits, K, N, seed=bits + cus)
+    try:
+        _lib.set_option("cu_count", cus)
+        _lib.set_option("mfma_wide_min_batch", 17)
+        p = _lib.plan_query(bits, K, N, batch=batch)
+        assert p["k_slices"] > 1 and p["dense_blocks"] == 27 // cus * cus + (27 % cus) * p["k_slices"]
+        x, mul, got = run_batched(qc, gpu, case, "dense", batch)
+    finally:
+        _lib.set_option("cu_count", 0)
+        _lib.set_option("mfma_wide_min_batch", 0)
+    assert H.rel_err(got, H.oracle_ref(case, x, mul, "dense")) <= TOL_FP64
+
+
 def _routing(mfma_min, cols_min, cols_max):
     from squeezellm_amd import _lib
 

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Build (here, no GPU needed) or run (on the GPU box) the ablation binaries of the wide matrix-core kernel.
+    python tools/experiments/wide_ablate/run.py build     # -> tools/experiments/wide_ablate/bin/<variant>
+    python tools/experiments/wide_ablate/run.py run       # prints one line per variant and configuration
+Each variant is a text patch of a COPY of csrc/sqllm_mfma_split.hip."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
+CSRC = os.path.join(ROOT, "squeezellm_amd", "csrc")
+SRC = os.path.join(CSRC, "sqllm_mfma_split.hip")
+BIN = os.path.join(HERE, "bin")
+
+LOADX_HEAD = "  auto load_x = [&](int g, int ph, u32x4 (&dx)[NX]) {\n    const int gu = group_unit(g);"
+LOADW_HEAD = "  auto load_w = [&](int g, u32x4 (&dw)[R]) {\n    const int u = clamp_unit(group_unit(g));"
+
+
+def patch(text, name):
+    wide = text.index("dense_role_mfma_wide(const void*")  # patches below apply from the wide role on (load_x / load_w) or to split_phase
+    head, tail = text[:wide], text[wide:]
+    if "noA" in name:  # vec values loaded for group 0 only
+        tail = tail.replace(LOADX_HEAD, LOADX_HEAD.replace("{\n", "{\n    if (g > 0 || ph > 0) return;\n", 1), 1)
+    if "noW" in name:  # weights loaded for groups 0 and 1 only
+        tail = tail.replace(LOADW_HEAD, LOADW_HEAD.replace("{\n", "{\n    if (g > 1) return;\n", 1), 1)
+    if "noLDS" in name:  # entries made up from the packed words instead of looked up
+        head = head.replace("      e[0] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C010400u) + off);",
+                            "      for (int i_ = 0; i_ < 8; ++i_) e[i_] = u32x2{lo + i_, hi ^ wmask};\n      if (lane_off == 0xFFFFFFFFu) e[0] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C010400u) + off);", 1)
+        for i in range(1, 8):
+            sel = ["lo", "hi"][i & 1]
+            old = f"      e[{i}] = lds_read_u32x2(__builtin_amdgcn_perm({sel}, lane_off, 0x0C010{4 + i // 2}00u) + off);\n"
+            assert old in head, old
+            head = head.replace(old, "", 1)
+    if "halfMFMA" in name:  # three of the partial products dropped
+        for op in ("Am, Bm", "Ah, Bl", "Ah, Bm"):
+            old = f"c = __builtin_amdgcn_mfma_f32_16x16x32_bf16({op}, c, 0, 0, 0);"
+            assert old in head
+            head = head.replace(old, "", 1)
+    if "noLut" in name:  # codebook values made up instead of gathered
+        old = "    ev[i] = lut[(size_t)c * L + (row % L)];"
+        assert old in tail
+        tail = tail.replace(old, "    ev[i] = 1e-3f * (float)(c + row);", 1)
+    if "noEpi" in name:
+        tail = tail.replace("  if (c0 < N) {  // (N is a multiple of 4", "  if (c0 < N && batch < 0) {  // (N is a multiple of 4", 1)
+    return head + tail
+
+
+VARIANTS = ["base", "noA", "noW", "noLDS", "noEpi", "noA_noW_noLDS_noEpi_noLut"]
+
+
+def build():
+    os.makedirs(BIN, exist_ok=True)
+    text = open(SRC).read()
+    for v in VARIANTS:
+        src = os.path.join(BIN, f"kernel_{v}.hip")
+        open(src, "w").write(patch(text, v))
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fno-gpu-rdc", f"-I{ROOT}/include", f"-I{CSRC}",
+               f'-DKERNEL_SOURCE="{src}"', f'-DVARIANT="{v}"', os.path.join(HERE, "harness.hip"), "-o", os.path.join(BIN, v)]
+        subprocess.check_call(cmd)
+        os.remove(src)
+        print("built", v, flush=True)
+
+
+def run():
+    for args in (["4", "2048", "0", "0"], ["4", "2048", "1", "0"]):
+        for v in VARIANTS:
+            subprocess.call([os.path.join(BIN, v)] + args)
+        print(flush=True)
+    for ks in ("1", "2"):
+        subprocess.call([os.path.join(BIN, "base"), "4", "2048", "0", ks])
+    for rows in ("64", "128", "256", "512", "1024"):
+        subprocess.call([os.path.join(BIN, "base"), "4", rows, "0", "0"])
+    subprocess.call([os.path.join(BIN, "base"), "3", "2048", "0", "0"])
+
+
+if __name__ == "__main__":
+    build() if sys.argv[1:] == ["build"] else run()
