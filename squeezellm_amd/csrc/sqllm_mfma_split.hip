@@ -379,6 +379,130 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
 }
 
 
+// ---- the wide form's phase: software-pipelined by hand ----
+// LDS byte addresses of the 8 weights of column J (0..3 of the lane's four) in phase PH of the unit whose words are t;
+// the column's table offset (J * kColStride) goes into the read's immediate field.  lane_off / wmask: see split_phase.
+template <int BITS>
+constexpr int kColStride = BITS == 4 ? 4096 : 2048;
+
+template <int BITS, int PH>
+__device__ __forceinline__ void col_addrs(const u32x4 (&t)[Fmt<BITS>::kRows], int J, uint32_t lane_off, uint32_t wmask, uint32_t (&a)[8]) {
+  if constexpr (BITS == 4) {
+    const uint32_t w = t[0][J];
+    const uint32_t lo = (w & 0x0F0F0F0Fu) | wmask, hi = ((w >> 4) & 0x0F0F0F0Fu) | wmask;
+    a[0] = __builtin_amdgcn_perm(lo, lane_off, 0x0C010400u);
+    a[1] = __builtin_amdgcn_perm(hi, lane_off, 0x0C010400u);
+    a[2] = __builtin_amdgcn_perm(lo, lane_off, 0x0C010500u);
+    a[3] = __builtin_amdgcn_perm(hi, lane_off, 0x0C010500u);
+    a[4] = __builtin_amdgcn_perm(lo, lane_off, 0x0C010600u);
+    a[5] = __builtin_amdgcn_perm(hi, lane_off, 0x0C010600u);
+    a[6] = __builtin_amdgcn_perm(lo, lane_off, 0x0C010700u);
+    a[7] = __builtin_amdgcn_perm(hi, lane_off, 0x0C010700u);
+  } else {
+    const uint32_t t0 = t[0][J], t1 = t[1][J], t2 = t[2][J];
+    a[0] = lane_off | field3_x256<8 * PH + 0>(t0, t1, t2);
+    a[1] = lane_off | field3_x256<8 * PH + 1>(t0, t1, t2);
+    a[2] = lane_off | field3_x256<8 * PH + 2>(t0, t1, t2);
+    a[3] = lane_off | field3_x256<8 * PH + 3>(t0, t1, t2);
+    a[4] = lane_off | field3_x256<8 * PH + 4>(t0, t1, t2);
+    a[5] = lane_off | field3_x256<8 * PH + 5>(t0, t1, t2);
+    a[6] = lane_off | field3_x256<8 * PH + 6>(t0, t1, t2);
+    a[7] = lane_off | field3_x256<8 * PH + 7>(t0, t1, t2);
+  }
+}
+
+// packed B operand word k of 12 ({hi x 4, mid x 4, lo x 4}) out of the 8 looked-up entries
+__device__ __forceinline__ uint32_t pack_b(const u32x2 (&e)[8], int k) {
+  const int i = k & 3, kind = k >> 2;
+  return kind == 0   ? __builtin_amdgcn_perm(e[2 * i + 1].x, e[2 * i].x, 0x05040100u)   // the low halves: hi parts
+         : kind == 1 ? __builtin_amdgcn_perm(e[2 * i + 1].x, e[2 * i].x, 0x07060302u)   // the high halves: mid parts
+                     : __builtin_amdgcn_perm(e[2 * i + 1].y, e[2 * i].y, 0x05040100u);
+}
+
+// One phase (8 k's of each lane row x the lane's four columns x 64 rows) of the wide form.  In split_phase a wave
+// alternates between looking a column up (addresses, 8 LDS reads, their latency, 12 packing instructions) and the 20-24
+// matrix instructions that use it -- with two waves per SIMD the matrix pipe was 65 % busy (profiles/r04_wide_pmc.txt).
+// Here the lookups of the NEXT column ride between the matrix instructions of the current one, slot by slot (a
+// scheduling barrier after each keeps the order): slot 0 its addresses, slots 2-5 two reads each, slots 8-19 one packing
+// instruction each.  B enters holding the packed operands of (t, PH, column 0) and leaves holding those of
+// (tn, PHN, column 0), the first column of the phase that follows.
+template <int BITS, int XMODE, int PH, int PHN>
+__device__ __forceinline__ void wide_phase(const u32x4 (&t)[Fmt<BITS>::kRows], const u32x4 (&tn)[Fmt<BITS>::kRows],
+                                           const u32x4 (&dx)[XMODE == 0 ? 8 : XMODE * 4], bool live, uint32_t lane_off, uint32_t wmask,
+                                           uint32_t (&B)[12], f32x4 (&acc)[4][4]) {
+  constexpr int MB = 4;
+  constexpr int NP = XMODE == 2 ? 5 : 6;  // partial products
+  uint32_t ah[MB][4], am[MB][4], al[MB][4];
+  if constexpr (XMODE == 0) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const f32x4 lo4 = __builtin_bit_cast(f32x4, dx[2 * mb]), hi4 = __builtin_bit_cast(f32x4, dx[2 * mb + 1]);
+      float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = live ? v[i] : 0.f;
+      split8(v, ah[mb], am[mb], al[mb]);
+    }
+  } else {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const u32x4 h4 = dx[XMODE * mb], m4 = dx[XMODE * mb + 1], l4 = dx[XMODE * mb + XMODE - 1];
+      ah[mb][0] = h4.x; ah[mb][1] = h4.y; ah[mb][2] = h4.z; ah[mb][3] = h4.w;
+      am[mb][0] = m4.x; am[mb][1] = m4.y; am[mb][2] = m4.z; am[mb][3] = m4.w;
+      al[mb][0] = l4.x; al[mb][1] = l4.y; al[mb][2] = l4.z; al[mb][3] = l4.w;  // (XMODE 2: not used)
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t a[8], Bn[12];
+    u32x2 e[8];
+    const uint32_t bh[4] = {B[0], B[1], B[2], B[3]}, bm[4] = {B[4], B[5], B[6], B[7]}, bl[4] = {B[8], B[9], B[10], B[11]};
+    const bf16x8 Bh = as_frag(bh), Bm = as_frag(bm), Bl = as_frag(bl);
+    const int jn = j < 3 ? j + 1 : 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int slot = MB * p + mb;
+        const bf16x8 Ah = as_frag(ah[mb]), Am = as_frag(am[mb]), Al = as_frag(al[mb]);
+        // small partial products first: Am Bm, Ah Bl, [Al Bh,] Ah Bm, Am Bh, Ah Bh
+        const int pp = (XMODE == 2 && p >= 2) ? p + 1 : p;
+        const bf16x8 A = (pp == 0 || pp == 4) ? Am : pp == 2 ? Al : Ah;
+        const bf16x8 Bx = (pp == 0 || pp == 3) ? Bm : pp == 1 ? Bl : Bh;
+        acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bx, acc[mb][j], 0, 0, 0);
+        if (slot == 0) {
+          if (j < 3) col_addrs<BITS, PH>(t, jn, lane_off, wmask, a);
+          else col_addrs<BITS, PHN>(tn, 0, lane_off, wmask, a);
+        }
+        if (slot >= 2 && slot < 6) {
+          e[2 * (slot - 2)] = lds_read_u32x2(a[2 * (slot - 2)] + jn * kColStride<BITS>);
+          e[2 * (slot - 2) + 1] = lds_read_u32x2(a[2 * (slot - 2) + 1] + jn * kColStride<BITS>);
+        }
+        if (slot >= 8 && slot < 20) {
+          // (order: the words that need the earliest reads first -- pair 0's hi, mid, lo, then pair 1's ...)
+          const int k = slot - 8, i = k / 3, kind = k % 3;
+          Bn[4 * kind + i] = pack_b(e, 4 * kind + i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) B[k] = Bn[k];
+  }
+}
+
+// packed operands of (t, PH, column 0) from scratch (a workgroup's first phase)
+template <int BITS, int PH>
+__device__ __forceinline__ void first_column(const u32x4 (&t)[Fmt<BITS>::kRows], uint32_t lane_off, uint32_t wmask, uint32_t (&B)[12]) {
+  uint32_t a[8];
+  u32x2 e[8];
+  col_addrs<BITS, PH>(t, 0, lane_off, wmask, a);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) e[i] = lds_read_u32x2(a[i]);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) B[k] = pack_b(e, k);
+}
+
 // ------------------------------------------------------------------------------------------------
 // 64 rows and more: the WIDE form.  The kernels above give a workgroup ONE 64-column tile and divide its k's between
 // the eight waves: every wave reads different vec values, nothing a wave loads is of use to another, and at 2048
@@ -501,49 +625,45 @@ __device__ __forceinline__ void dense_role_mfma_wide(const void* __restrict__ xv
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  using P0 = std::integral_constant<int, 0>;
-  using P1 = std::integral_constant<int, 1>;
-  using P2 = std::integral_constant<int, 2>;
-  using P3 = std::integral_constant<int, 3>;
-  auto phase = [&](const u32x4 (&t)[R], auto ph_tag, const u32x4 (&dx)[NX], int g) {
-    split_phase<BITS, MB, XMODE, decltype(ph_tag)::value>(t, dx, group_unit(g) < u_end, lane_off, wmask, acc);
-  };
-  // group g out of (w = its words, xcur = its phase-0 values); w is refilled with group g + 2's words once a copy is taken.
-  // Loads return in order: the vec loads of the next phase go out BEFORE the far-ahead weight load, so that waiting for
-  // them does not mean waiting for it.
-  auto decode_group = [&](int g, u32x4 (&w)[R], u32x4 (&xcur)[NX], u32x4 (&xn)[NX], u32x4 (&xo)[NX]) {
+  // group g out of (w = its words, wn = the next group's, xcur = its phase-0 values); w is refilled with group g + 2's
+  // words once a copy is taken.  Loads return in order: the vec loads of the next phase go out BEFORE the far-ahead
+  // weight load, so that waiting for them does not mean waiting for it.
+  uint32_t Bst[12];  // packed B operands of the upcoming phase's first column (wide_phase)
+  first_column<BITS, 0>(wa, lane_off, wmask, Bst);
+  auto decode_group = [&](int g, u32x4 (&w)[R], const u32x4 (&wn)[R], u32x4 (&xcur)[NX], u32x4 (&xn)[NX], u32x4 (&xo)[NX]) {
     u32x4 t[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) t[r] = w[r];
+    const bool live = group_unit(g) < u_end;
     if constexpr (NPH == 1) {
       load_x(g + 1, 0, xn);
       load_w(g + 2, w);
       __builtin_amdgcn_sched_barrier(0);
-      phase(t, P0{}, xcur, g);
+      wide_phase<BITS, XMODE, 0, 0>(t, wn, xcur, live, lane_off, wmask, Bst, acc);
     } else {
       load_x(g, 1, xo);
       load_w(g + 2, w);
       __builtin_amdgcn_sched_barrier(0);
-      phase(t, P0{}, xcur, g);
+      wide_phase<BITS, XMODE, 0, 1>(t, t, xcur, live, lane_off, wmask, Bst, acc);
       load_x(g, 2, xcur);
       __builtin_amdgcn_sched_barrier(0);
-      phase(t, P1{}, xo, g);
+      wide_phase<BITS, XMODE, 1, 2>(t, t, xo, live, lane_off, wmask, Bst, acc);
       load_x(g, 3, xo);
       __builtin_amdgcn_sched_barrier(0);
-      phase(t, P2{}, xcur, g);
+      wide_phase<BITS, XMODE, 2, 3>(t, t, xcur, live, lane_off, wmask, Bst, acc);
       load_x(g + 1, 0, xn);
       __builtin_amdgcn_sched_barrier(0);
-      phase(t, P3{}, xo, g);
+      wide_phase<BITS, XMODE, 3, 0>(t, wn, xo, live, lane_off, wmask, Bst, acc);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
   for (int g = 0; g < n_g; g += 2) {
     if constexpr (NPH == 1) {
-      decode_group(g, wa, xa, xb, xb);
-      decode_group(g + 1, wb, xb, xa, xa);
+      decode_group(g, wa, wb, xa, xb, xb);
+      decode_group(g + 1, wb, wa, xb, xa, xa);
     } else {
-      decode_group(g, wa, xa, xa, xb);
-      decode_group(g + 1, wb, xa, xa, xb);
+      decode_group(g, wa, wb, xa, xa, xb);
+      decode_group(g + 1, wb, wa, xa, xa, xb);
     }
   }
   // ---- results: lane (i16, grp) holds rows 16 mb + 4 grp + {x, y, z, w} of columns 4 i16 + j.  A workgroup that covered

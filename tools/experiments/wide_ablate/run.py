@@ -46,7 +46,7 @@ def patch(text, name):
     return head + tail
 
 
-VARIANTS = ["base", "noA", "noW", "noLDS", "noEpi", "noA_noW_noLDS_noEpi_noLut"]
+VARIANTS = ["base", "noA", "noW", "noEpi"]
 
 
 def build():
