@@ -208,7 +208,6 @@ void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch
 // into as many K slices as fill the idle CUs (their workgroups add atomically).  dense_blocks = workgroups of the 1-D
 // grid = full_units + (units - full_units) * k_slices; units_per_wg = units of K per slice.
 constexpr int kWideTiles = 8;
-constexpr int kWideMinBatch = 512;  // (13B shapes: from 512 rows the wide form wins -- 418 -> 299-360 us; at 128 rows it loses, 104 -> 158-169: profiles/r04_wide_first.txt)
 int make_plan_wide(const sqllm_op* op, sqllm::KernelGeom* gm) {  // returns full_units
   make_plan(op, gm, 1);
   const int row_blocks = (gm->batch + 63) / 64;
@@ -235,10 +234,17 @@ int make_plan_wide(const sqllm_op* op, sqllm::KernelGeom* gm) {  // returns full
   return (int)full;
 }
 
+// The wide form pays once its units (64 rows x 8 column tiles) fill most of the chip: 13B shapes, profiles/r04_wide_product.txt
+// -- 5120x13824 at 512 rows (216 units) 424 -> 280-337 us, every 13B shape at 2048 rows 1.58-1.66 -> 1.04-1.26 ms
+// (5120x5120: 642 -> 453-520 us); at 80 units (5120x5120, 512 rows) it loses, 150 -> 182-199 us.  An explicit
+// mfma_wide_min_batch is taken at its word.
 bool takes_wide_path(const sqllm_op* op) {
-  int from = knobs().mfma_wide_min_batch.load(std::memory_order_relaxed);
-  if (from == 0) from = kWideMinBatch;
-  return op->batch >= from && knobs().mfma_split.load(std::memory_order_relaxed) != 0;
+  if (!knobs().mfma_split.load(std::memory_order_relaxed)) return false;
+  const int from = knobs().mfma_wide_min_batch.load(std::memory_order_relaxed);
+  if (from > 0) return op->batch >= from;
+  const long long col_groups = ((op->N + sqllm::kTileN - 1) / sqllm::kTileN + kWideTiles - 1) / kWideTiles;
+  const long long units = col_groups * ((op->batch + 63) / 64);
+  return op->batch >= 64 && 5 * units >= 4 * (long long)cu_count();
 }
 
 int mfma_min_batch_of(const sqllm_op* op) {
@@ -475,12 +481,11 @@ struct TransposedVec {
 };
 
 // The wide matrix-core kernel takes vec split ONCE into bf16 planes (sqllm_mfma_split.hip: sqllm_split_vec).  Same kind
-// of scratch as TransposedVec: 6 bytes per element of vec (rows padded to 64) plus a zero block and the flag words;
+// of scratch as TransposedVec: 6 bytes per element of vec (rows padded to 64) plus a zero k block per 16 rows and the flag words;
 // without scratch the kernel splits in registers.
 constexpr int kSplitPlanesMinBatch = 64;
 struct SplitVec {
   void* planes = nullptr;
-  uint32_t zero_chunk = 0;
   uint32_t* flags = nullptr;
   hipStream_t s = nullptr;
   int acquire(const sqllm_op* ops, sqllm_stream_t stream, hipEvent_t* e0) {
@@ -504,9 +509,8 @@ struct SplitVec {
       return SQLLM_OK;
     }
     planes = p;
-    zero_chunk = (uint32_t)sqllm::split_planes_zero_chunk(ops[0].batch, ops[0].K);
     flags = reinterpret_cast<uint32_t*>(static_cast<char*>(p) + chunks * 16);
-    const hipError_t e = sqllm::split_vec(ops[0].vec, planes, zero_chunk, flags, ops[0].batch, ops[0].K, s, e0 ? *e0 : nullptr);
+    const hipError_t e = sqllm::split_vec(ops[0].vec, planes, flags, ops[0].batch, ops[0].K, s, e0 ? *e0 : nullptr);
     if (e != hipSuccess) return static_cast<int>(e);  // (the destructor frees)
     if (e0) *e0 = nullptr;  // (a profiled group starts with its split)
     return SQLLM_OK;
@@ -625,7 +629,6 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       a.xT = (op->nnz > 0 && op->rows && op->cols && op->vals) ? xT : nullptr;
       a.Bp = Bp;
       a.planes = sv.planes;
-      a.plane_zero_chunk = sv.zero_chunk;
       a.plane_flags = sv.flags;
       a.ga.n_seg = 1;
       memset(a.ga.seg, 0, sizeof(a.ga.seg));

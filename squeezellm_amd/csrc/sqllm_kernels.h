@@ -106,7 +106,6 @@ struct LaunchArgs {
   int Bp = 0;
   // wide-batch launches on the split matrix-core kernel: vec already split into bf16 planes (split_vec), or null
   const void* planes = nullptr;
-  uint32_t plane_zero_chunk = 0;     // split_planes_zero_chunk(batch, K)
   const uint32_t* plane_flags = nullptr;  // kSplitFlagWgs words: any non-zero lo part?
   bool wide = false;  // the geometry is make_plan_wide's: workgroups of eight column tiles (sqllm_mfma_split.hip: sqllm_fused_wide)
   int wide_full_units = 0;  // ... and this many of them over all of K; the rest in gm.k_slices slices
@@ -157,11 +156,10 @@ hipError_t launch_batched_mfma(int bits, const LaunchArgs& a, hipStream_t stream
 hipError_t launch_batched_mfma_split(int bits, const LaunchArgs& a, hipStream_t stream);  // bf16 matrix instructions on exactly split operands (sqllm_mfma_split.hip)
 hipError_t launch_batched_cols(int bits, const LaunchArgs& a, hipStream_t stream);
 constexpr int kSplitFlagWgs = 256;  // workgroups (and flag words) of split_vec
-// planes of split_vec, in 16-byte chunks: 3 planes x 64 lanes per (16 rows, 32 k's), rows padded to a multiple of 64,
-// one all-zero triple of blocks at the end (at split_planes_zero_chunk)
-inline uint64_t split_planes_zero_chunk(int batch, int K) { return (uint64_t)((batch + 63) / 64 * 4) * (uint64_t)(K / 32) * 192u; }
-inline uint64_t split_planes_chunks(int batch, int K) { return split_planes_zero_chunk(batch, K) + 192u; }
-hipError_t split_vec(const float* x, void* planes, uint32_t zero_chunk, uint32_t* flags, int batch, int K, hipStream_t stream, hipEvent_t ev_start);
+// planes of split_vec, in 16-byte chunks: 3 planes x 64 lanes per (16 rows, 32 k's); rows padded to a multiple of 64, every
+// block of 16 rows K / 32 + 1 k blocks long, the last one all zero
+inline uint64_t split_planes_chunks(int batch, int K) { return (uint64_t)((batch + 63) / 64 * 4) * (uint64_t)(K / 32 + 1) * 192u; }
+hipError_t split_vec(const float* x, void* planes, uint32_t* flags, int batch, int K, hipStream_t stream, hipEvent_t ev_start);
 constexpr int kSmallSplitRows = 16;  // rows up to which a group of ops runs as ONE launch on the split matrix-core kernel (all three terms)
 hipError_t launch_small_split(int bits, const LaunchArgs& a, hipStream_t stream);
 hipError_t transpose_vec(const float* x, float* xT, int batch, int K, int Bp, hipStream_t stream, hipEvent_t ev_start);

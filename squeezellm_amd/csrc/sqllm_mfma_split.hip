@@ -34,7 +34,8 @@
 // The WIDE form (64 rows and more, sqllm_fused_wide below) takes vec split ONCE, by its own kernel (sqllm_split_vec), into
 // bf16 planes in stream-ordered scratch, laid out in FRAGMENT order: a 1-KB block per (16 rows, 32 k's, plane) holds the
 // 64 lanes' 16-byte A fragments back to back, blocks ordered [row block][k block][plane hi, mid, lo] -- a wave's load is
-// 1 KB contiguous, and no value is split more than once (in the kernels above: once per 64-column tile).  The split
+// 1 KB contiguous, and no value is split more than once (in the kernels above: once per 64-column tile).  Every row
+// block ends in an all-zero k block: the address of lane rows past the end of a K range.  The split
 // kernel also reports whether any `lo` part is non-zero; where none is (vec came from fp16 values, as in
 // QuantLinearLUT.forward: 11 significant bits fit hi + mid) the lo plane is neither read nor multiplied (five partial
 // products instead of six).
@@ -517,7 +518,7 @@ __device__ __forceinline__ void first_column(const u32x4 (&t)[Fmt<BITS>::kRows],
 constexpr int kWideTiles = 8;  // column tiles per workgroup = waves
 
 template <int BITS, int XMODE>
-__device__ __forceinline__ void dense_role_mfma_wide(const void* __restrict__ xv, uint32_t zero_chunk, const u32x4* __restrict__ q,
+__device__ __forceinline__ void dense_role_mfma_wide(const void* __restrict__ xv, const u32x4* __restrict__ q,
                                                      float* __restrict__ y, const float* __restrict__ lut, int K, int N, int batch,
                                                      int m0, int ct, int u_beg, int u_end, bool atomic) {
   using F = Fmt<BITS>;
@@ -527,7 +528,7 @@ __device__ __forceinline__ void dense_role_mfma_wide(const void* __restrict__ xv
   constexpr int NX = XMODE == 0 ? 2 * MB : XMODE * MB;
   constexpr int kCbBytes = split_codebook_bytes(BITS);
   const float* x = static_cast<const float*>(xv);
-  const u32x4* xc = static_cast<const u32x4*>(xv);  // (planes: 16-byte chunks)
+  const uint32_t KB = (uint32_t)K / 32;
   __builtin_amdgcn_s_waitcnt(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -537,20 +538,21 @@ __device__ __forceinline__ void dense_role_mfma_wide(const void* __restrict__ xv
   const char* qbase = reinterpret_cast<const char*>(q);
   const uint32_t row_bytes = 16u * (uint32_t)row_stride;
   int xrow[MB];        // fp32 vec: this lane's batch rows (rows past the batch re-read its last row; never stored)
-  uint32_t xblk[MB];   // planes: first chunk of the row block's k block 0
+  const char* xblk[MB];   // planes: the row block's k block 0 (wave-uniform: a scalar base for the loads)
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     int r = m0 + 16 * mb + i16;
     if (r > batch - 1) r = batch - 1;
     xrow[mb] = r * K;
-    xblk[mb] = (uint32_t)(m0 / 16 + mb) * (uint32_t)(K / 32) * 192u;
+    xblk[mb] = static_cast<const char*>(xv) + (size_t)(m0 / 16 + mb) * (KB + 1) * 3072;
   }
   const int col0 = ct * kTileN;
   const uint32_t wbase = (uint32_t)wave * (uint32_t)kCbBytes;  // this wave's table
   const uint32_t slot = 8 * (i16 + 16 * (grp & 1));
   // (see split_phase: a 4-bit table base is 16 KB * wave -- bits 14, 15 ride in the index bytes, bit 16 in byte 1 of lane_off)
   const uint32_t lane_off = BITS == 4 ? (slot | ((wbase >> 16) << 8)) : (wbase + slot);
-  const uint32_t wmask = BITS == 4 ? 0x01010101u * ((wbase >> 8) & 0xC0u) : 0u;
+  uint32_t wmask = BITS == 4 ? 0x01010101u * ((wbase >> 8) & 0xC0u) : 0u;
+  asm volatile("" : "+v"(wmask));  // (in a vector register: (w & 0x0F0F0F0F) | wmask is then ONE v_and_or_b32 -- two scalar operands would not encode)
 
   // ---- this wave's codebook values: entry e = lane + 64 i of the tile's 4 * L * 32 eight-byte entries ----
   constexpr int NST = 4 * L * 32 / 64;
@@ -590,15 +592,15 @@ __device__ __forceinline__ void dense_role_mfma_wide(const void* __restrict__ xv
       }
     } else {
       // fragment order (sqllm_split_vec): 4-bit -- the group's 32 k's are ONE k block, lane for lane; 3-bit -- a lane
-      // row's unit is a k block of its own, phase ph = its quarter
-      const bool live = gu < u_end;
-      const uint32_t kb = BITS == 4 ? (uint32_t)u >> 2 : (uint32_t)u;
+      // row's unit is a k block of its own, phase ph = its quarter.  One 32-bit byte offset serves all row blocks and
+      // planes (scalar base per row block, the plane in the immediate field); past the K range: the zero k block.
+      const uint32_t kb = gu < u_end ? (BITS == 4 ? (uint32_t)u >> 2 : (uint32_t)u) : KB;
       const uint32_t lp = BITS == 4 ? (uint32_t)lane : (uint32_t)(16 * ph + i16);
+      const uint32_t off = 3072u * kb + 16u * lp;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const uint32_t c = live ? xblk[mb] + 192u * kb + lp : zero_chunk + lp;
 #pragma unroll
-        for (int pl = 0; pl < XMODE; ++pl) dx[XMODE * mb + pl] = xc[c + 64u * pl];
+        for (int pl = 0; pl < XMODE; ++pl) dx[XMODE * mb + pl] = *reinterpret_cast<const u32x4*>(xblk[mb] + off + 1024 * pl);
       }
     }
   };
@@ -715,22 +717,21 @@ sqllm_fused_batched_split(const float* x, const GroupArgs ga) {
 
 // ------------------------------------------------------------------------------------------------
 // vec split once into bf16 planes in fragment order (see the header).  Chunk = 16 bytes = 8 k's of one row; chunk index
-//   ((rb * (K / 32) + kb) * 3 + plane) * 64 + lane,   lane = 16 * ((k / 8) % 4) + row % 16,  rb = row / 16, kb = k / 32,
-// rows padded with zeros to a multiple of 64, and one all-zero (rb, kb) triple of blocks at the very end (`zero_chunk`:
-// where lanes past the end of a K range read).  flags[w] = 1 if workgroup w met a non-zero lo part; the grid is always
-// kSplitFlagWgs workgroups, so the consumer ORs a fixed number of flags and nothing needs zeroing beforehand.
+//   ((rb * (K / 32 + 1) + kb) * 3 + plane) * 64 + lane,   lane = 16 * ((k / 8) % 4) + row % 16,  rb = row / 16, kb = k / 32,
+// rows padded with zeros to a multiple of 64, k block K / 32 of every row block all zero.  flags[w] = 1 if workgroup w
+// met a non-zero lo part; the grid is always kSplitFlagWgs workgroups, so the consumer ORs a fixed number of flags and
+// nothing needs zeroing beforehand.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) sqllm_split_vec(const float* __restrict__ x, u32x4* __restrict__ planes, uint32_t zero_chunk,
+__global__ void __launch_bounds__(256) sqllm_split_vec(const float* __restrict__ x, u32x4* __restrict__ planes, uint32_t n_frag,
                                                        uint32_t* __restrict__ flags, int batch, int K) {
-  const uint32_t KB = (uint32_t)K / 32;
-  const uint32_t n_frag = zero_chunk / 3 + 64;  // (rb, kb, lane) triples, the zero triple included
+  const uint32_t KB1 = (uint32_t)K / 32 + 1;
   uint32_t any = 0;
-  for (uint32_t f = blockIdx.x * 256 + threadIdx.x; f < n_frag; f += kSplitFlagWgs * 256) {
-    const uint32_t lane = f & 63, blk = f >> 6;  // blk = rb * KB + kb
-    const uint32_t rb = blk / KB, kb = blk - rb * KB;
+  for (uint32_t f = blockIdx.x * 256 + threadIdx.x; f < n_frag; f += kSplitFlagWgs * 256) {  // f = (rb, kb, lane)
+    const uint32_t lane = f & 63, blk = f >> 6;
+    const uint32_t rb = blk / KB1, kb = blk - rb * KB1;
     const uint32_t row = 16 * rb + (lane & 15), k = 32 * kb + 8 * (lane >> 4);
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (row < (uint32_t)batch && 192 * blk < zero_chunk) {
+    if (row < (uint32_t)batch && kb + 1 < KB1) {
       const float* p = x + (size_t)row * K + k;
       const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -754,7 +755,7 @@ __global__ void __launch_bounds__(256) sqllm_split_vec(const float* __restrict__
 // CU -- are cut into gm.k_slices K slices of gm.units_per_wg units, one workgroup each (make_plan_wide).
 template <int BITS, bool XP>
 __global__ void __launch_bounds__(kWaves * 64, 2)
-sqllm_fused_wide(const void* xv, uint32_t zero_chunk, const uint32_t* flags, int full_units, const GroupArgs ga) {
+sqllm_fused_wide(const void* xv, const uint32_t* flags, int full_units, const GroupArgs ga) {
   __shared__ __attribute__((aligned(16))) char lds[kWideTiles * split_codebook_bytes(BITS)];
   static_assert(kWaves == kWideTiles, "one column tile per wave");
   const Segment sg = ga.seg[0];
@@ -783,10 +784,10 @@ sqllm_fused_wide(const void* xv, uint32_t zero_chunk, const uint32_t* flags, int
     static_assert(kSplitFlagWgs == 256, "four flags per lane");
     const uint32_t f = flags[lane] | flags[lane + 64] | flags[lane + 128] | flags[lane + 192];
     const bool has_lo = __builtin_amdgcn_ballot_w64(f != 0) != 0;
-    if (has_lo) dense_role_mfma_wide<BITS, 3>(xv, zero_chunk, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced);
-    else dense_role_mfma_wide<BITS, 2>(xv, zero_chunk, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced);
+    if (has_lo) dense_role_mfma_wide<BITS, 3>(xv, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced);
+    else dense_role_mfma_wide<BITS, 2>(xv, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced);
   } else {
-    dense_role_mfma_wide<BITS, 0>(xv, 0, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced);
+    dense_role_mfma_wide<BITS, 0>(xv, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced);
   }
 }
 
@@ -866,13 +867,13 @@ hipError_t launch_wide_bits(const LaunchArgs& a, hipStream_t stream) {
   if (a.planes) {
     auto kern = sqllm_fused_wide<BITS, true>;
     if (a.ev_start || a.ev_stop)
-      hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, a.planes, a.plane_zero_chunk, a.plane_flags, a.wide_full_units, a.ga);
-    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.planes, a.plane_zero_chunk, a.plane_flags, a.wide_full_units, a.ga);
+      hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, a.planes, a.plane_flags, a.wide_full_units, a.ga);
+    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.planes, a.plane_flags, a.wide_full_units, a.ga);
   } else {
     auto kern = sqllm_fused_wide<BITS, false>;
     const uint32_t* none = nullptr;
-    if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, a.x, 0u, none, a.wide_full_units, a.ga);
-    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.x, 0u, none, a.wide_full_units, a.ga);
+    if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, a.x, none, a.wide_full_units, a.ga);
+    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.x, none, a.wide_full_units, a.ga);
   }
   return hipGetLastError();
 }
@@ -897,10 +898,11 @@ hipError_t launch_small_split(int bits, const LaunchArgs& a, hipStream_t stream)
 }
 
 // vec [batch, K] -> bf16 planes in fragment order + lo flags (sqllm_split_vec); `planes` holds split_planes_chunks(batch, K) chunks
-hipError_t split_vec(const float* x, void* planes, uint32_t zero_chunk, uint32_t* flags, int batch, int K, hipStream_t stream, hipEvent_t ev_start) {
+hipError_t split_vec(const float* x, void* planes, uint32_t* flags, int batch, int K, hipStream_t stream, hipEvent_t ev_start) {
   u32x4* out = static_cast<u32x4*>(planes);
-  if (ev_start) hipExtLaunchKernelGGL(sqllm_split_vec, dim3(kSplitFlagWgs), dim3(256), 0, stream, ev_start, nullptr, 0, x, out, zero_chunk, flags, batch, K);
-  else hipLaunchKernelGGL(sqllm_split_vec, dim3(kSplitFlagWgs), dim3(256), 0, stream, x, out, zero_chunk, flags, batch, K);
+  const uint32_t n_frag = (uint32_t)(split_planes_chunks(batch, K) / 3);  // (rb, kb, lane) triples
+  if (ev_start) hipExtLaunchKernelGGL(sqllm_split_vec, dim3(kSplitFlagWgs), dim3(256), 0, stream, ev_start, nullptr, 0, x, out, n_frag, flags, batch, K);
+  else hipLaunchKernelGGL(sqllm_split_vec, dim3(kSplitFlagWgs), dim3(256), 0, stream, x, out, n_frag, flags, batch, K);
   return hipGetLastError();
 }
 

@@ -99,7 +99,7 @@ def test_plan_geometry():
     assert _lib.plan_query(4, 4096, 4096, batch=9)["grid_y"] == 1
     assert _lib.plan_query(4, 4096, 4096, batch=33)["grid_y"] == 1
     assert _lib.plan_query(4, 4096, 4096, batch=511)["grid_y"] == 8
-    # from 512 rows the WIDE form: a 1-D grid over units of 64 rows x 8 column tiles, whole rounds of one unit per CU over
+    # once its units fill 80 % of the CUs the WIDE form: a 1-D grid over units of 64 rows x 8 column tiles, whole rounds of one unit per CU over
     # all of K, the last partial round cut into K slices (csrc/sqllm_capi.hip: make_plan_wide)
     pq = _lib.plan_query(4, 4096, 4096, batch=2048)  # 32 row blocks x 8 column groups = 256 units: exactly one round
     assert pq["grid_y"] == 1 and pq["dense_blocks"] == 256 and pq["k_slices"] == 1
@@ -337,8 +337,8 @@ def test_range_plans_cover_every_unit_exactly_once():
                     U = K // (8 if bits == 4 else 32)
                     upw, blocks, tiles, ks = p["groups_per_wave"], p["dense_blocks"], p["col_tiles"], p["k_slices"]
                     assert upw >= 1 and blocks >= 1
-                    if batch >= 512:  # the wide form: units of 64 rows x 8 column tiles; whole rounds unsliced, the rest in ks slices
-                        units = -(-tiles // 8) * -(-batch // 64)
+                    units = -(-tiles // 8) * -(-batch // 64)
+                    if batch >= 64 and 5 * units >= 4 * 256:  # the wide form (its units fill 80 % of the CUs): whole rounds unsliced, the rest in ks slices
                         full = units // 256 * 256
                         assert blocks == full + (units - full) * ks and upw % 4 == 0, (bits, K, N, batch, p)
                         assert ks * upw >= U > (ks - 1) * upw, (bits, K, N, batch, p)

@@ -23,9 +23,8 @@ int main(int argc, char** argv) {
   std::vector<float> hl((size_t)N * L);
   for (auto& v : hl) { st = st * 1664525u + 1013904223u; v = ((int)(st >> 8) % 2001 - 1000) * 2e-5f; }
   const size_t chunks = sqllm::split_planes_chunks(batch, K);
-  const uint32_t plane = (uint32_t)sqllm::split_planes_zero_chunk(batch, K);  // (the kernel's zero_chunk argument)
   std::vector<uint16_t> hp(8 * chunks);
-  for (size_t i = 0; i < hp.size(); ++i) { st = st * 1664525u + 1013904223u; hp[i] = i / 8 >= plane ? 0 : (uint16_t)(0x3c00 + (st >> 24)); }
+  for (size_t i = 0; i < hp.size(); ++i) { st = st * 1664525u + 1013904223u; hp[i] = (i / 8 / 192) % (K / 32 + 1) == (size_t)(K / 32) ? 0 : (uint16_t)(0x3c00 + (st >> 24)); }
   std::vector<uint32_t> hf(sqllm::kSplitFlagWgs, has_lo ? 1u : 0u);
   uint32_t* dq; float* dl; uint16_t* dp; uint32_t* df; float* dy;
   CK(hipMalloc(&dq, qwords * 4)); CK(hipMalloc(&dl, hl.size() * 4)); CK(hipMalloc(&dp, hp.size() * 2)); CK(hipMalloc(&df, hf.size() * 4));
@@ -62,8 +61,8 @@ int main(int argc, char** argv) {
   float best = 1e30f;
   for (int rep = 0; rep < 4; ++rep) {
     CK(hipEventRecord(e0, 0));
-    if (bits == 4) hipLaunchKernelGGL((sqllm::sqllm_fused_wide<4, true>), grid, dim3(512), 0, 0, (const void*)dp, plane, (const uint32_t*)df, full, ga);
-    else hipLaunchKernelGGL((sqllm::sqllm_fused_wide<3, true>), grid, dim3(512), 0, 0, (const void*)dp, plane, (const uint32_t*)df, full, ga);
+    if (bits == 4) hipLaunchKernelGGL((sqllm::sqllm_fused_wide<4, true>), grid, dim3(512), 0, 0, (const void*)dp, (const uint32_t*)df, full, ga);
+    else hipLaunchKernelGGL((sqllm::sqllm_fused_wide<3, true>), grid, dim3(512), 0, 0, (const void*)dp, (const uint32_t*)df, full, ga);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));

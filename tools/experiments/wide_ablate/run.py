@@ -46,7 +46,7 @@ def patch(text, name):
     return head + tail
 
 
-VARIANTS = ["base", "noA", "noW", "noEpi"]
+VARIANTS = ["base"]
 
 
 def build():
