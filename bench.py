@@ -643,10 +643,31 @@ def batch_leg_13b(dev, args, sync):
                             "hbm_frac_wall": round(sum(bytes_per_op) / n_layers / (ms_layer * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "per_layer_us": per_shape_table(seq, layers, bytes_per_op, us)}
         del xs, ys, seq, graph
+    # B = 2048: the batch the reference's perplexity evaluation feeds the *_batched ops (and what a prompt looks like) --
+    # one decoder layer, eager launches (the wide matrix-core kernel splits vec into stream-ordered scratch), events per op
+    B = 2048
+    one = layers[:7]
+    xs, ys = decoder_inputs(one, dev, gen, batch=B)
+    seq = decode.OpSequence(one, xs, ys, batched=True, fuse_shared_input=not args.no_fuse)
+    seq.launch()
+    sync()
+    walls = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        seq.launch()
+        sync()
+        walls.append(time.perf_counter() - t0)
+    seq.profile(reps=1)
+    us = seq.profile(reps=3)
+    flops = sum(2.0 * B * l["K"] * l["N"] for l in one)
+    rec["rows2048"] = {"ms_per_decoder_layer": round(min(walls) * 1e3, 4), "dense_TFLOPs_wall": round(flops / min(walls) / 1e12, 1),
+                       "vec": "fp16-born (as QuantLinearLUT.forward passes it)",
+                       "per_layer_us": per_shape_table(seq, one, [synth.layer_bytes(l, B) for l in one], us)}
+    del xs, ys, seq
     del layers
     torch.cuda.empty_cache()
     return {"workload": f"llama-13b w4 s45 (0.45% CSR outliers + top-10 rows), {n_layers} decoder layers x 7 linears of distinct weights, "
-                        "batch 1 = matvec op, batch 2/4/8/16 = *_batched op, HIP-graph replay", **rec}
+                        "batch 1 = matvec op, batch 2/4/8/16 = *_batched op, HIP-graph replay; rows2048: one layer at 2048 rows, eager", **rec}
 
 
 def main():

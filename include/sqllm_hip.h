@@ -72,11 +72,11 @@ typedef struct sqllm_op {
 } sqllm_op;
 
 /* Enqueue  mul += W_lut . vec (+ CSR . vec) (+ full_rows^T . vec scattered)  on `stream`: one fused
- * kernel for batch <= 8.  A wider batch ("mfma_min_batch" rows and more) is up to three kernels -- a
- * transpose of vec into stream-ordered scratch (hipMallocAsync / hipFreeAsync on `stream`; only with
- * a CSR term; inside a stream capture they become memory nodes of the graph unless option
- * "scratch_in_capture" is 0), the sparse terms, the dense term on the matrix cores.  No host
- * synchronisation in either case. */
+ * kernel up to 16 rows.  A wider batch is up to four kernels -- a transpose of vec into stream-ordered
+ * scratch (hipMallocAsync / hipFreeAsync on `stream`; only with a CSR term), the sparse terms, (wide
+ * form only: "mfma_wide_min_batch") the split of vec into bf16 planes, again in such scratch, and
+ * the dense term on the matrix cores.  Inside a stream capture the scratch becomes memory nodes of
+ * the graph unless option "scratch_in_capture" is 0.  No host synchronisation in either case. */
 int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream);
 
 /* Enqueue `n_ops` ops back to back on `stream` from one host call (a decode pass over a stack of
@@ -286,6 +286,17 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *   "mfma_fuse_small" 1 (default, with mfma_split): from mfma_min_batch up to 16 rows an op -- or a whole GROUP of ops over one vec
  *                     (sqllm_launch_group) -- is ONE launch of the split matrix-core kernel with its CSR / top-X workgroups in
  *                     the same grid; 0: one launch per op plus a launch for its sparse terms (as from 17 rows on)
+ *   "mfma_wide_min_batch"  0 (default): with mfma_split, the WIDE form of that kernel -- workgroups of eight 64-column tiles, one per
+ *                     wave, all on the same k's: the vec values of a step are fetched once per workgroup instead of once per tile --
+ *                     takes over once its units (64 rows x 8 column tiles) fill 80 % of the CUs (13B shapes: 512-2048 rows; 2048
+ *                     rows 1.6-1.7 -> 1.0-1.3 ms); n > 0: from n rows on, whatever the shape; a huge value: never.  Geometry
+ *                     through sqllm_plan_query: grid_y = 1, dense_blocks = workgroups (whole rounds of units over all of K +
+ *                     the last round's units in k_slices K slices of groups_per_wave units).
+ *   "split_planes_min_batch"  0 (default: 64): rows from which the wide form takes vec split ONCE into bf16 planes in stream-ordered
+ *                     scratch (6 bytes per vec value, rows padded to 64; a split kernel in front of the op; fp16-born vec -- what
+ *                     QuantLinearLUT.forward passes -- then costs five partial products instead of six); below, or without
+ *                     scratch (scratch_in_capture = 0 while capturing, allocation failure), every wave splits its values in
+ *                     registers; a huge value: never.
  *   "validate_csr"    debugging aid, default 0.  1 = before every launch that carries a CSR term,
  *                     check ON THE DEVICE that rows[] is non-decreasing with rows[0] == 0 and
  *                     rows[N] == nnz, and return SQLLM_E_SPARSE otherwise.  Blocks the host (one
