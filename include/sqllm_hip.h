@@ -288,15 +288,17 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     the same grid; 0: one launch per op plus a launch for its sparse terms (as from 17 rows on)
  *   "mfma_wide_min_batch"  0 (default): with mfma_split, the WIDE form of that kernel -- workgroups of eight 64-column tiles, one per
  *                     wave, all on the same k's: the vec values of a step are fetched once per workgroup instead of once per tile --
- *                     takes over once its units (64 rows x 8 column tiles) fill 80 % of the CUs (13B shapes: 512-2048 rows; 2048
- *                     rows 1.6-1.7 -> 1.0-1.3 ms); n > 0: from n rows on, whatever the shape; a huge value: never.  Geometry
- *                     through sqllm_plan_query: grid_y = 1, dense_blocks = workgroups (whole rounds of units over all of K +
- *                     the last round's units in k_slices K slices of groups_per_wave units).
+ *                     takes over from 64 rows up once batch * K * N >= 5.7e9 (3-bit: 4e9; three times that while the stream is
+ *                     capturing; without scratch: once its units of 64 rows x 8 tiles fill 80 % of the CUs).  13B shapes: 128
+ *                     rows 104 -> 85 us, 2048 rows 1.66 -> 0.96 ms.  n > 0: from n rows on, whatever the shape; a huge value:
+ *                     never.  Geometry through sqllm_plan_query: grid_y = 1, dense_blocks = workgroups (whole rounds of units
+ *                     over all of K + the last round's units in k_slices K slices of groups_per_wave units, whose sums a
+ *                     second launch adds to mul).
  *   "split_planes_min_batch"  0 (default: 64): rows from which the wide form takes vec split ONCE into bf16 planes in stream-ordered
- *                     scratch (6 bytes per vec value, rows padded to 64; a split kernel in front of the op; fp16-born vec -- what
+ *                     scratch (6 bytes per vec value, rows padded to 64, plus 16 KB per K slice and tile; a split kernel in front of the op; fp16-born vec -- what
  *                     QuantLinearLUT.forward passes -- then costs five partial products instead of six); below, or without
  *                     scratch (scratch_in_capture = 0 while capturing, allocation failure), every wave splits its values in
- *                     registers; a huge value: never.
+ *                     registers and K slices add atomically; a huge value: never.
  *   "validate_csr"    debugging aid, default 0.  1 = before every launch that carries a CSR term,
  *                     check ON THE DEVICE that rows[] is non-decreasing with rows[0] == 0 and
  *                     rows[N] == nnz, and return SQLLM_E_SPARSE otherwise.  Blocks the host (one

@@ -234,17 +234,25 @@ int make_plan_wide(const sqllm_op* op, sqllm::KernelGeom* gm) {  // returns full
   return (int)full;
 }
 
-// The wide form pays once its units (64 rows x 8 column tiles) fill most of the chip: 13B shapes, profiles/r04_wide_product.txt
-// -- 5120x13824 at 512 rows (216 units) 424 -> 280-337 us, every 13B shape at 2048 rows 1.58-1.66 -> 1.04-1.26 ms
-// (5120x5120: 642 -> 453-520 us); at 80 units (5120x5120, 512 rows) it loses, 150 -> 182-199 us.  An explicit
+// When the wide form pays (13B shapes, 64-2048 rows, profiles/r04_wide_slabs.txt).  With vec as planes and the K slices'
+// sums as slabs it beats the tile kernel (~175 dense-equivalent TFLOP/s at any size) once the op is ~65 us of that: 4-bit
+// batch * K * N >= 5.7e9 (5120x13824: 128 rows 104 -> 85 us, 256 rows 206 -> 145, 2048 rows 1.66 -> 0.96 ms; 5120x5120: 256
+// rows 75 -> 71, below that it loses), 3-bit >= 4e9 (its tile kernel is slower: 64 rows 71 -> 62).  Inside a stream capture
+// the scratch costs an allocation and a free node (~25 us per group): three times that.  WITHOUT scratch (vec split in
+// registers, slices add atomically) only once its units fill 80 % of the CUs (5120x13824: from 512 rows).  An explicit
 // mfma_wide_min_batch is taken at its word.
-bool takes_wide_path(const sqllm_op* op) {
+bool takes_wide_path(const sqllm_op* op, bool with_scratch, bool capturing) {
   if (!knobs().mfma_split.load(std::memory_order_relaxed)) return false;
   const int from = knobs().mfma_wide_min_batch.load(std::memory_order_relaxed);
   if (from > 0) return op->batch >= from;
+  if (op->batch < 64) return false;
+  if (with_scratch) {
+    const double work = (double)op->batch * op->K * op->N;
+    return work >= (op->bits == 4 ? 5.7e9 : 4e9) * (capturing ? 3.0 : 1.0);
+  }
   const long long col_groups = ((op->N + sqllm::kTileN - 1) / sqllm::kTileN + kWideTiles - 1) / kWideTiles;
   const long long units = col_groups * ((op->batch + 63) / 64);
-  return op->batch >= 64 && 5 * units >= 4 * (long long)cu_count();
+  return 5 * units >= 4 * (long long)cu_count();
 }
 
 int mfma_min_batch_of(const sqllm_op* op) {
@@ -411,7 +419,7 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   if (op->K <= 0 || op->N <= 0 || (op->K % 32) != 0 || (op->N % 4) != 0) return SQLLM_E_SHAPE;
   sqllm::KernelGeom gm;
   const bool mfma = takes_mfma_path(op);
-  const bool wide = mfma && takes_wide_path(op);
+  const bool wide = mfma && takes_wide_path(op, true, false);  // (as launched outside a capture, scratch at hand)
   if (wide) (void)make_plan_wide(op, &gm);
   else if (mfma) make_plan_mfma(op, &gm);
   else if (takes_cols_path(op)) make_plan_cols(op, &gm);
@@ -436,87 +444,86 @@ int64_t sqllm_linear_workspace_bytes(const sqllm_op* op) {
   return align16(8ll * (op->batch <= 0 ? 1 : op->batch) * op->N);
 }
 
-// Batched ops with a CSR term want vec TRANSPOSED (xT[k][row]: one coalesced read per non-zero serves every batch
-// row, instead of `batch` gathers 4 K bytes apart).  The copy lives in stream-ordered scratch (hipMallocAsync /
-// hipFreeAsync on the caller's stream: no host synchronisation, the pool keeps the block for the next call; inside a
-// stream capture the allocation and the free become memory nodes of the graph -- works under torch's graph capture
-// on ROCm 7.2; option scratch_in_capture = 0 keeps captures allocation-free).  Without scratch the role falls back
-// to gathering from vec itself.
-struct TransposedVec {
+// Stream-ordered scratch of a wide-batch group (hipMallocAsync / hipFreeAsync on the caller's stream: no host
+// synchronisation, the pool keeps the block for the next call; inside a stream capture the allocation and the free become
+// memory nodes of the graph -- works under torch's graph capture on ROCm 7.2; option scratch_in_capture = 0 keeps
+// captures allocation-free).  ONE block per group holds
+//   xT     vec TRANSPOSED (xT[k][row]) for the CSR role: one coalesced read per non-zero serves every batch row instead
+//          of `batch` gathers 4 K bytes apart (only with a CSR term; option sparse_transpose);
+//   planes vec split once into bf16 planes in fragment order + the lo flags (sqllm_mfma_split.hip: sqllm_split_vec) for
+//          the wide form (from split_planes_min_batch rows, default 64);
+//   slabs  the sums of the wide form's K slices (sqllm_wide_reduce adds them to mul).
+// Without scratch: the CSR role gathers from vec, the wide form splits in registers and its slices add atomically.
+constexpr int kSplitPlanesMinBatch = 64;
+struct WideScratch {
+  void* block = nullptr;
   float* xT = nullptr;
   int Bp = 0;
+  void* planes = nullptr;
+  uint32_t* flags = nullptr;
+  float* slabs = nullptr;
+  bool capturing = false;
   hipStream_t s = nullptr;
-  // enqueues the transpose of ops[0].vec if any op of the group has a CSR term and scratch can be had; *e0 (the
-  // start event of a profiled group) goes to the transpose kernel if there is one
+  // ops[0] is validated; *e0 (the start event of a profiled group) goes to the first kernel enqueued here, if any
   int acquire(const sqllm_op* ops, int n, sqllm_stream_t stream, hipEvent_t* e0) {
     s = static_cast<hipStream_t>(stream);
-    bool any_csr = false;
-    for (int i = 0; i < n; ++i) any_csr = any_csr || (ops[i].nnz > 0 && ops[i].rows && ops[i].cols && ops[i].vals);
-    if (!any_csr || !ops[0].vec || ops[0].batch <= 0 || ops[0].K <= 0 || !knobs().sparse_transpose.load(std::memory_order_relaxed))
-      return SQLLM_OK;
-    if (!knobs().scratch_in_capture.load(std::memory_order_relaxed)) {
-      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      if (!(hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone)) {
-        (void)hipGetLastError();
-        return SQLLM_OK;
-      }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (!(hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone)) {
+      (void)hipGetLastError();
+      capturing = true;
     }
+    if (capturing && !knobs().scratch_in_capture.load(std::memory_order_relaxed)) return SQLLM_OK;
+    if (!ops[0].vec || ops[0].batch <= 0 || ops[0].K <= 0) return SQLLM_OK;
+    bool any_csr = false, any_wide = false;
+    uint64_t slab_bytes = 0;
+    for (int i = 0; i < n; ++i) {
+      any_csr = any_csr || (ops[i].nnz > 0 && ops[i].rows && ops[i].cols && ops[i].vals);
+      if (validate(&ops[i]) != SQLLM_OK || !takes_wide_path(&ops[i], true, capturing)) continue;  // (the launch loop reports errors)
+      any_wide = true;
+      sqllm::KernelGeom gm;  // room for the K slices' sums (the ops of a group run one after the other: the largest need serves all)
+      const int full = make_plan_wide(&ops[i], &gm);
+      const uint64_t b = sqllm::wide_slab_bytes(gm.dense_blocks, full, gm.k_slices);
+      if (b > slab_bytes) slab_bytes = b;
+    }
+    const bool want_xT = any_csr && knobs().sparse_transpose.load(std::memory_order_relaxed);
+    int from = knobs().split_planes_min_batch.load(std::memory_order_relaxed);
+    if (from == 0) from = kSplitPlanesMinBatch;
+    const uint64_t chunks = sqllm::split_planes_chunks(ops[0].batch, ops[0].K);
+    const bool want_planes = any_wide && ops[0].batch >= from && chunks < (1ull << 31);  // (32-bit chunk numbers in the kernel)
+    if (!want_xT && !want_planes) return SQLLM_OK;
     Bp = (ops[0].batch + 63) / 64 * 64;
+    const uint64_t xt_bytes = want_xT ? (uint64_t)ops[0].K * Bp * sizeof(float) : 0;
+    const uint64_t plane_bytes = want_planes ? chunks * 16 : 0;
+    const uint64_t flag_bytes = want_planes ? (sqllm::kSplitFlagWgs * sizeof(uint32_t) + 15) / 16 * 16 : 0;
+    if (!want_planes) slab_bytes = 0;
     keep_scratch_in_pool();
-    void* p = nullptr;
-    if (hipMallocAsync(&p, (size_t)ops[0].K * Bp * sizeof(float), s) != hipSuccess || !p) {
-      (void)hipGetLastError();  // no scratch: gather from vec
+    if (hipMallocAsync(&block, xt_bytes + plane_bytes + flag_bytes + slab_bytes, s) != hipSuccess || !block) {
+      (void)hipGetLastError();  // no scratch
+      block = nullptr;
       Bp = 0;
       return SQLLM_OK;
     }
-    xT = static_cast<float*>(p);
-    const hipError_t e = sqllm::transpose_vec(ops[0].vec, xT, ops[0].batch, ops[0].K, Bp, s, e0 ? *e0 : nullptr);
-    if (e != hipSuccess) return static_cast<int>(e);  // (the destructor frees)
-    if (e0) *e0 = nullptr;  // (a profiled group starts with its transpose)
+    char* p = static_cast<char*>(block);
+    if (want_xT) {
+      xT = reinterpret_cast<float*>(p);
+      const hipError_t e = sqllm::transpose_vec(ops[0].vec, xT, ops[0].batch, ops[0].K, Bp, s, e0 ? *e0 : nullptr);
+      if (e != hipSuccess) return static_cast<int>(e);  // (the destructor frees)
+      if (e0) *e0 = nullptr;
+    } else {
+      Bp = 0;
+    }
+    if (want_planes) {
+      planes = p + xt_bytes;
+      flags = reinterpret_cast<uint32_t*>(p + xt_bytes + plane_bytes);
+      if (slab_bytes) slabs = reinterpret_cast<float*>(p + xt_bytes + plane_bytes + flag_bytes);
+      const hipError_t e = sqllm::split_vec(ops[0].vec, planes, flags, ops[0].batch, ops[0].K, s, e0 ? *e0 : nullptr);
+      if (e != hipSuccess) return static_cast<int>(e);
+      if (e0) *e0 = nullptr;
+    }
     return SQLLM_OK;
   }
-  ~TransposedVec() {
-    if (xT) (void)hipFreeAsync(xT, s);
-  }
-};
-
-// The wide matrix-core kernel takes vec split ONCE into bf16 planes (sqllm_mfma_split.hip: sqllm_split_vec).  Same kind
-// of scratch as TransposedVec: 6 bytes per element of vec (rows padded to 64) plus a zero k block per 16 rows and the flag words;
-// without scratch the kernel splits in registers.
-constexpr int kSplitPlanesMinBatch = 64;
-struct SplitVec {
-  void* planes = nullptr;
-  uint32_t* flags = nullptr;
-  hipStream_t s = nullptr;
-  int acquire(const sqllm_op* ops, sqllm_stream_t stream, hipEvent_t* e0) {
-    s = static_cast<hipStream_t>(stream);
-    int from = knobs().split_planes_min_batch.load(std::memory_order_relaxed);
-    if (from == 0) from = kSplitPlanesMinBatch;
-    if (ops[0].batch < from || !ops[0].vec || ops[0].K <= 0) return SQLLM_OK;
-    const uint64_t chunks = sqllm::split_planes_chunks(ops[0].batch, ops[0].K);
-    if (chunks >= (1ull << 31)) return SQLLM_OK;  // 32-bit chunk numbers in the kernel
-    if (!knobs().scratch_in_capture.load(std::memory_order_relaxed)) {
-      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      if (!(hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone)) {
-        (void)hipGetLastError();
-        return SQLLM_OK;
-      }
-    }
-    keep_scratch_in_pool();
-    void* p = nullptr;
-    if (hipMallocAsync(&p, chunks * 16 + sqllm::kSplitFlagWgs * sizeof(uint32_t), s) != hipSuccess || !p) {
-      (void)hipGetLastError();  // no scratch: split in registers
-      return SQLLM_OK;
-    }
-    planes = p;
-    flags = reinterpret_cast<uint32_t*>(static_cast<char*>(p) + chunks * 16);
-    const hipError_t e = sqllm::split_vec(ops[0].vec, planes, flags, ops[0].batch, ops[0].K, s, e0 ? *e0 : nullptr);
-    if (e != hipSuccess) return static_cast<int>(e);  // (the destructor frees)
-    if (e0) *e0 = nullptr;  // (a profiled group starts with its split)
-    return SQLLM_OK;
-  }
-  ~SplitVec() {
-    if (planes) (void)hipFreeAsync(planes, s);
+  ~WideScratch() {
+    if (block) (void)hipFreeAsync(block, s);
   }
 };
 
@@ -586,7 +593,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       block += (sg.gm.dense_block0 + sg.gm.dense_blocks + 7) / 8 * 8;
     }
     for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
-    // (The CSR chunks gather from vec itself here.  Handing them a transposed copy -- TransposedVec, as the wider
+    // (The CSR chunks gather from vec itself here.  Handing them a transposed copy -- WideScratch::xT, as the wider
     // batches get -- was measured: no faster at 8 / 16 rows in the sum of the kernels (13B s45 layer 168 vs 155 us at 8
     // rows), and inside a captured graph the scratch's allocation / free nodes cost ~25 us per group: 258 vs 150 us per
     // layer.  profiles/r04_small_batch_layer.txt)
@@ -596,24 +603,15 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     // batched operators: one launch per op (the members of a group only share their input) of the
     // matrix-core kernel (wide batches) or of the column-lane kernel (small ones)
     const bool mfma = takes_mfma_path(&ops[0]);
-    // Wide batches with a CSR term: the role wants vec TRANSPOSED (lane = batch row: one coalesced
-    // read per non-zero instead of `batch` gathers).  The copy lives in stream-ordered scratch
-    // (hipMallocAsync / hipFreeAsync on the caller's stream: no host synchronisation, the pool keeps
-    // the block for the next call).  Without scratch the role falls back to gathering from vec itself.
-    TransposedVec tv;
+    WideScratch ws;  // (transposed vec for the CSR role, planes + slabs for the wide form: see the struct)
     if (mfma) {
-      const int rc = tv.acquire(ops, n, stream, &e0);
+      int rc = validate(&ops[0]);  // (its kernels read vec by batch and K: shape errors first)
+      if (rc != SQLLM_OK) return rc;
+      rc = ws.acquire(ops, n, stream, &e0);
       if (rc != SQLLM_OK) return rc;
     }
-    SplitVec sv;
-    if (mfma && takes_wide_path(&ops[0])) {
-      int rc = validate(&ops[0]);  // (the split kernel reads vec by K: shape errors first)
-      if (rc != SQLLM_OK) return rc;
-      rc = sv.acquire(ops, stream, &e0);
-      if (rc != SQLLM_OK) return rc;
-    }
-    float* const xT = tv.xT;
-    const int Bp = tv.Bp;
+    float* const xT = ws.xT;
+    const int Bp = ws.Bp;
     for (int i = 0; i < n; ++i) {
       const sqllm_op* op = &ops[i];
       int rc = validate(op);
@@ -628,8 +626,9 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       a.x = op->vec;
       a.xT = (op->nnz > 0 && op->rows && op->cols && op->vals) ? xT : nullptr;
       a.Bp = Bp;
-      a.planes = sv.planes;
-      a.plane_flags = sv.flags;
+      a.planes = ws.planes;
+      a.plane_flags = ws.flags;
+      a.wide_slabs = ws.slabs;
       a.ga.n_seg = 1;
       memset(a.ga.seg, 0, sizeof(a.ga.seg));
       sqllm::Segment& sg = a.ga.seg[0];
@@ -641,7 +640,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       sg.vals = op->vals;
       sg.full_rows = op->topX > 0 ? op->full_rows : nullptr;
       sg.full_idx = op->topX > 0 ? op->full_row_indices : nullptr;
-      a.wide = mfma && takes_wide_path(op);
+      a.wide = mfma && takes_wide_path(op, ws.planes != nullptr, ws.capturing);
       if (a.wide) a.wide_full_units = make_plan_wide(op, &sg.gm);
       else if (mfma) make_plan_mfma(op, &sg.gm);
       else make_plan_cols(op, &sg.gm);

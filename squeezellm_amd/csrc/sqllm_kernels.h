@@ -109,6 +109,7 @@ struct LaunchArgs {
   const uint32_t* plane_flags = nullptr;  // kSplitFlagWgs words: any non-zero lo part?
   bool wide = false;  // the geometry is make_plan_wide's: workgroups of eight column tiles (sqllm_mfma_split.hip: sqllm_fused_wide)
   int wide_full_units = 0;  // ... and this many of them over all of K; the rest in gm.k_slices slices
+  float* wide_slabs = nullptr;  // scratch for the slices' sums (wide_slab_bytes), or null: they add atomically
 };
 
 // ---- streaming batch-1 kernel (sqllm_stream.hip) ----
@@ -159,6 +160,10 @@ constexpr int kSplitFlagWgs = 256;  // workgroups (and flag words) of split_vec
 // planes of split_vec, in 16-byte chunks: 3 planes x 64 lanes per (16 rows, 32 k's); rows padded to a multiple of 64, every
 // block of 16 rows K / 32 + 1 k blocks long, the last one all zero
 inline uint64_t split_planes_chunks(int batch, int K) { return (uint64_t)((batch + 63) / 64 * 4) * (uint64_t)(K / 32 + 1) * 192u; }
+// scratch for the sums of the wide form's K slices: 64 x 64 floats per slice and column tile
+inline uint64_t wide_slab_bytes(int dense_blocks, int full_units, int k_slices) {
+  return k_slices > 1 ? (uint64_t)(dense_blocks - full_units) * 8u * 64u * 64u * 4u : 0;
+}
 hipError_t split_vec(const float* x, void* planes, uint32_t* flags, int batch, int K, hipStream_t stream, hipEvent_t ev_start);
 constexpr int kSmallSplitRows = 16;  // rows up to which a group of ops runs as ONE launch on the split matrix-core kernel (all three terms)
 hipError_t launch_small_split(int bits, const LaunchArgs& a, hipStream_t stream);

@@ -516,11 +516,12 @@ __device__ __forceinline__ void first_column(const u32x4 (&t)[Fmt<BITS>::kRows],
 // adds its 64 x 64 results straight to mul.  Grid: x = (group of 8 column tiles, K slice), y = block of 64 rows.
 // ------------------------------------------------------------------------------------------------
 constexpr int kWideTiles = 8;  // column tiles per workgroup = waves
+constexpr int kWideSlabFloats = 64 * kTileN;  // a wave's 64 x 64 sums
 
 template <int BITS, int XMODE>
 __device__ __forceinline__ void dense_role_mfma_wide(const void* __restrict__ xv, const u32x4* __restrict__ q,
                                                      float* __restrict__ y, const float* __restrict__ lut, int K, int N, int batch,
-                                                     int m0, int ct, int u_beg, int u_end, bool atomic) {
+                                                     int m0, int ct, int u_beg, int u_end, bool atomic, float* __restrict__ slab) {
   using F = Fmt<BITS>;
   constexpr int MB = 4;
   constexpr int L = F::kLut, R = F::kRows, KU = F::kK;
@@ -673,7 +674,16 @@ __device__ __forceinline__ void dense_role_mfma_wide(const void* __restrict__ xv
   // 16-byte read-add-write; K slices add atomically -- the L2 takes ~1.2 fp32 atomics per clock and channel, 57 M of them
   // (13B gate/up, 2048 rows, two slices) were 177 us of a 1.39-ms kernel (profiles/r04_wide_ablate.txt).
   const int c0 = col0 + 4 * i16;
-  if (c0 < N) {  // (N is a multiple of 4: the lane's four columns exist together)
+  if (slab) {
+    // a K slice with scratch: its 64 x 64 sums go out as a 16-KB slab in lane order (16 stores of 1 KB per wave); the
+    // launch that follows (sqllm_wide_reduce) adds a tile's slabs to mul.  Adding them here atomically cost 74 of 151 us
+    // at 128 rows, 68 of 208 at 256 (profiles/r04_wide_ablate_midrows.txt).
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        *reinterpret_cast<f32x4*>(slab + (size_t)((mb * 4 + e) * 64 + lane) * 4) = f32x4{acc[mb][0][e], acc[mb][1][e], acc[mb][2][e], acc[mb][3][e]};
+  } else if (c0 < N) {  // (N is a multiple of 4: the lane's four columns exist together)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       const int r0 = m0 + 16 * mb + 4 * grp;
@@ -755,23 +765,25 @@ __global__ void __launch_bounds__(256) sqllm_split_vec(const float* __restrict__
 // CU -- are cut into gm.k_slices K slices of gm.units_per_wg units, one workgroup each (make_plan_wide).
 template <int BITS, bool XP>
 __global__ void __launch_bounds__(kWaves * 64, 2)
-sqllm_fused_wide(const void* xv, const uint32_t* flags, int full_units, const GroupArgs ga) {
+sqllm_fused_wide(const void* xv, const uint32_t* flags, int full_units, float* slabs, const GroupArgs ga) {
   __shared__ __attribute__((aligned(16))) char lds[kWideTiles * split_codebook_bytes(BITS)];
   static_assert(kWaves == kWideTiles, "one column tile per wave");
   const Segment sg = ga.seg[0];
-  asm volatile("" ::SQLLM_SEG_OPERANDS(sg), "s"(xv), "s"(flags), "s"(full_units));
+  asm volatile("" ::SQLLM_SEG_OPERANDS(sg), "s"(xv), "s"(flags), "s"(full_units), "s"(slabs));
   __builtin_amdgcn_sched_barrier(0);
   const KernelGeom& gm = sg.gm;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   int unit = blockIdx.x, u_beg = 0, u_end = gm.units_total;
   const bool sliced = unit >= full_units && gm.k_slices > 1;
+  float* slab = nullptr;
   if (sliced) {
     const int t = unit - full_units;
     const int q = t / gm.k_slices;
     unit = full_units + q;
     u_beg = (t - q * gm.k_slices) * gm.units_per_wg;
     if (u_end > u_beg + gm.units_per_wg) u_end = u_beg + gm.units_per_wg;
+    if (slabs) slab = slabs + ((size_t)t * kWideTiles + wave) * kWideSlabFloats;  // [sliced unit][slice][wave]
   }
   const int col_groups = (gm.col_tiles + kWideTiles - 1) / kWideTiles;
   const int rb = unit / col_groups, cg = unit - rb * col_groups;
@@ -784,10 +796,40 @@ sqllm_fused_wide(const void* xv, const uint32_t* flags, int full_units, const Gr
     static_assert(kSplitFlagWgs == 256, "four flags per lane");
     const uint32_t f = flags[lane] | flags[lane + 64] | flags[lane + 128] | flags[lane + 192];
     const bool has_lo = __builtin_amdgcn_ballot_w64(f != 0) != 0;
-    if (has_lo) dense_role_mfma_wide<BITS, 3>(xv, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced);
-    else dense_role_mfma_wide<BITS, 2>(xv, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced);
+    if (has_lo) dense_role_mfma_wide<BITS, 3>(xv, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced, slab);
+    else dense_role_mfma_wide<BITS, 2>(xv, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced, slab);
   } else {
-    dense_role_mfma_wide<BITS, 0>(xv, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced);
+    dense_role_mfma_wide<BITS, 0>(xv, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced, slab);
+  }
+}
+
+// The K slices of the wide form's last round leave their sums as slabs (one per slice and wave = 64 x 64 tile, in the
+// writing wave's lane order: element (16 mb + 4 grp + e, 4 i16 .. + 3) at float4 index (4 mb + e) * 64 + lane); this
+// launch adds a tile's slabs to mul.  One workgroup of 256 threads per (sliced unit, wave).
+__global__ void __launch_bounds__(256) sqllm_wide_reduce(const float* __restrict__ slabs, float* __restrict__ y, int N, int batch, int col_tiles,
+                                                         int full_units, int k_slices) {
+  const int uq = blockIdx.x / kWideTiles, w = blockIdx.x - uq * kWideTiles;
+  const int col_groups = (col_tiles + kWideTiles - 1) / kWideTiles;
+  const int unit = full_units + uq;
+  const int rb = unit / col_groups, cg = unit - rb * col_groups;
+  const int ct = cg * kWideTiles + w;
+  if (ct >= col_tiles) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + 256 * i;  // float4 index inside a slab
+    const int lane = idx & 63, me = idx >> 6;
+    const int row = rb * 64 + 16 * (me >> 2) + 4 * (lane >> 4) + (me & 3), col = ct * kTileN + 4 * (lane & 15);
+    f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < k_slices; ++sl) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + (((size_t)uq * k_slices + sl) * kWideTiles + w) * kWideSlabFloats + (size_t)idx * 4);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    if (row < batch && col < N) {
+      f32x4* p = reinterpret_cast<f32x4*>(y + (size_t)row * N + col);
+      f32x4 o = *p;
+      o.x += sum.x; o.y += sum.y; o.z += sum.z; o.w += sum.w;
+      *p = o;
+    }
   }
 }
 
@@ -864,17 +906,25 @@ template <int BITS>
 hipError_t launch_wide_bits(const LaunchArgs& a, hipStream_t stream) {
   const KernelGeom& gm = a.ga.seg[0].gm;
   dim3 grid(gm.dense_blocks);
+  const int sliced_units = gm.k_slices > 1 ? (gm.dense_blocks - a.wide_full_units) / gm.k_slices : 0;
+  float* slabs = sliced_units > 0 ? a.wide_slabs : nullptr;
+  hipEvent_t stop = slabs ? nullptr : a.ev_stop;  // (with slabs the op ends with the reduce launch)
   if (a.planes) {
     auto kern = sqllm_fused_wide<BITS, true>;
-    if (a.ev_start || a.ev_stop)
-      hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, a.planes, a.plane_flags, a.wide_full_units, a.ga);
-    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.planes, a.plane_flags, a.wide_full_units, a.ga);
+    if (a.ev_start || stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, stop, 0, a.planes, a.plane_flags, a.wide_full_units, slabs, a.ga);
+    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.planes, a.plane_flags, a.wide_full_units, slabs, a.ga);
   } else {
     auto kern = sqllm_fused_wide<BITS, false>;
     const uint32_t* none = nullptr;
-    if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, a.x, none, a.wide_full_units, a.ga);
-    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.x, none, a.wide_full_units, a.ga);
+    if (a.ev_start || stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, stop, 0, a.x, none, a.wide_full_units, slabs, a.ga);
+    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.x, none, a.wide_full_units, slabs, a.ga);
   }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || !slabs) return e;
+  const Segment& sg = a.ga.seg[0];
+  dim3 rgrid(sliced_units * kWideTiles);
+  if (a.ev_stop) hipExtLaunchKernelGGL(sqllm_wide_reduce, rgrid, dim3(256), 0, stream, nullptr, a.ev_stop, 0, (const float*)slabs, sg.y, gm.N, gm.batch, gm.col_tiles, a.wide_full_units, gm.k_slices);
+  else hipLaunchKernelGGL(sqllm_wide_reduce, rgrid, dim3(256), 0, stream, (const float*)slabs, sg.y, gm.N, gm.batch, gm.col_tiles, a.wide_full_units, gm.k_slices);
   return hipGetLastError();
 }
 

@@ -98,9 +98,10 @@ def test_plan_geometry():
     assert _lib.plan_query(3, 4096, 4096, batch=17)["grid_y"] == 1
     assert _lib.plan_query(4, 4096, 4096, batch=9)["grid_y"] == 1
     assert _lib.plan_query(4, 4096, 4096, batch=33)["grid_y"] == 1
-    assert _lib.plan_query(4, 4096, 4096, batch=511)["grid_y"] == 8
-    # once its units fill 80 % of the CUs the WIDE form: a 1-D grid over units of 64 rows x 8 column tiles, whole rounds of one unit per CU over
-    # all of K, the last partial round cut into K slices (csrc/sqllm_capi.hip: make_plan_wide)
+    assert _lib.plan_query(4, 4096, 4096, batch=320)["grid_y"] == 5  # batch * K * N = 5.4e9: still the tile kernel, passes of 64 rows
+    # from batch * K * N = 5.7e9 (4-bit; 3-bit 4e9) the WIDE form: a 1-D grid over units of 64 rows x 8 column tiles, whole rounds of one unit per
+    # CU over all of K, the last partial round cut into K slices (csrc/sqllm_capi.hip: takes_wide_path, make_plan_wide)
+    assert _lib.plan_query(4, 4096, 4096, batch=340)["grid_y"] == 1 and _lib.plan_query(3, 4096, 4096, batch=240)["grid_y"] == 1
     pq = _lib.plan_query(4, 4096, 4096, batch=2048)  # 32 row blocks x 8 column groups = 256 units: exactly one round
     assert pq["grid_y"] == 1 and pq["dense_blocks"] == 256 and pq["k_slices"] == 1
     pm = _lib.plan_query(4, 5120, 13824, batch=16)
@@ -338,7 +339,7 @@ def test_range_plans_cover_every_unit_exactly_once():
                     upw, blocks, tiles, ks = p["groups_per_wave"], p["dense_blocks"], p["col_tiles"], p["k_slices"]
                     assert upw >= 1 and blocks >= 1
                     units = -(-tiles // 8) * -(-batch // 64)
-                    if batch >= 64 and 5 * units >= 4 * 256:  # the wide form (its units fill 80 % of the CUs): whole rounds unsliced, the rest in ks slices
+                    if batch >= 64 and batch * K * N >= (5.7e9 if bits == 4 else 4e9):  # the wide form: whole rounds unsliced, the rest in ks slices
                         full = units // 256 * 256
                         assert blocks == full + (units - full) * ks and upw % 4 == 0, (bits, K, N, batch, p)
                         assert ks * upw >= U > (ks - 1) * upw, (bits, K, N, batch, p)

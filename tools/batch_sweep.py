@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--sparse-transpose", type=int, default=1, help="0: the wide-batch CSR role gathers from vec itself")
     ap.add_argument("--total-mb", type=float, default=600.0)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--vec", default="fp16", choices=["fp16", "fp32"], help="fp16: vec values born in fp16 (what forward passes); fp32: full-mantissa values")
     ap.add_argument("--check", action="store_true", help="parity of the matrix-core path vs the oracle on a small shape")
     args = ap.parse_args()
     import numpy as np
@@ -68,7 +69,8 @@ def main():
     layers = [synth.make_layer(K, N, args.bits, sparse_frac=args.sparse, topX=args.topx if args.sparse > 0 else 0,
                                heavy_rows=10 if args.sparse > 0 else 0, device=dev, seed=i) for i in range(copies)]
     for B in map(int, args.batches.split(",")):
-        xs = [torch.randn((B, K), device=dev) for _ in layers]
+        # (fp16-born vec, as QuantLinearLUT.forward passes it: x.float() of a half tensor; --vec fp32 for full-mantissa values)
+        xs = [torch.randn((B, K), device=dev) if args.vec == "fp32" else torch.randn((B, K), device=dev, dtype=torch.float16).float() for _ in layers]
         ys = [torch.zeros((B, N), device=dev) for _ in layers]
         nbytes = synth.layer_bytes(layers[0], B)
         for path in args.paths.split(","):

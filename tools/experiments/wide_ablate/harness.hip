@@ -61,8 +61,8 @@ int main(int argc, char** argv) {
   float best = 1e30f;
   for (int rep = 0; rep < 4; ++rep) {
     CK(hipEventRecord(e0, 0));
-    if (bits == 4) hipLaunchKernelGGL((sqllm::sqllm_fused_wide<4, true>), grid, dim3(512), 0, 0, (const void*)dp, (const uint32_t*)df, full, ga);
-    else hipLaunchKernelGGL((sqllm::sqllm_fused_wide<3, true>), grid, dim3(512), 0, 0, (const void*)dp, (const uint32_t*)df, full, ga);
+    if (bits == 4) hipLaunchKernelGGL((sqllm::sqllm_fused_wide<4, true>), grid, dim3(512), 0, 0, (const void*)dp, (const uint32_t*)df, full, (float*)nullptr, ga);
+    else hipLaunchKernelGGL((sqllm::sqllm_fused_wide<3, true>), grid, dim3(512), 0, 0, (const void*)dp, (const uint32_t*)df, full, (float*)nullptr, ga);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));

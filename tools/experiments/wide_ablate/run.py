@@ -46,7 +46,7 @@ def patch(text, name):
     return head + tail
 
 
-VARIANTS = ["base"]
+VARIANTS = ["base", "noEpi", "noLut", "noEpi_noLut", "noA_noW_noLDS_noEpi_noLut"]
 
 
 def build():
@@ -63,15 +63,10 @@ def build():
 
 
 def run():
-    for args in (["4", "2048", "0", "0"], ["4", "2048", "1", "0"]):
+    for args in (["4", "128", "0", "0"], ["4", "256", "0", "0"], ["4", "128", "0", "2"], ["4", "2048", "0", "0"]):
         for v in VARIANTS:
             subprocess.call([os.path.join(BIN, v)] + args)
         print(flush=True)
-    for ks in ("1", "2"):
-        subprocess.call([os.path.join(BIN, "base"), "4", "2048", "0", ks])
-    for rows in ("64", "128", "256", "512", "1024"):
-        subprocess.call([os.path.join(BIN, "base"), "4", rows, "0", "0"])
-    subprocess.call([os.path.join(BIN, "base"), "3", "2048", "0", "0"])
 
 
 if __name__ == "__main__":
