@@ -555,16 +555,18 @@ __device__ __forceinline__ void dense_role_mfma_wide(const void* __restrict__ xv
   uint32_t wmask = BITS == 4 ? 0x01010101u * ((wbase >> 8) & 0xC0u) : 0u;
   asm volatile("" : "+v"(wmask));  // (in a vector register: (w & 0x0F0F0F0F) | wmask is then ONE v_and_or_b32 -- two scalar operands would not encode)
 
-  // ---- this wave's codebook values: entry e = lane + 64 i of the tile's 4 * L * 32 eight-byte entries ----
-  constexpr int NST = 4 * L * 32 / 64;
-  float ev[NST];
+  // ---- this wave's codebook: lane = column of the tile, its L values as L / 4 sixteen-byte loads (the tile's block of
+  // the table is contiguous: 64 columns x L floats).  Gathering entry by entry in LDS order -- 32 scattered loads per
+  // lane, as the tile kernels do with 512 threads -- cost 92 us of a 1.03-ms launch at 2048 rows: every workgroup of a
+  // round builds its tables at the same moment (profiles/r04_wide_ablate_midrows.txt, noLut). ----
+  constexpr int NLV = L / 4;
+  f32x4 lv[NLV];
+  {
+    int c = col0 + lane;
+    if (c > N - 1) c = N - 1;  // (columns past N: the last one again; never stored)
+    const f32x4* lp = reinterpret_cast<const f32x4*>(lut + (size_t)c * L);
 #pragma unroll
-  for (int i = 0; i < NST; ++i) {
-    const int e = lane + 64 * i;
-    const int row = e >> 5, sl = e & 31;
-    int c = col0 + 4 * (sl & 15) + row / L;
-    if (c > N - 1) c = N - 1;
-    ev[i] = lut[(size_t)c * L + (row % L)];
+    for (int i = 0; i < NLV; ++i) lv[i] = lp[i];
   }
   const int n_g = (u_end - u_beg + 3) / 4;
   int cidx = col0 / 4 + i16;
@@ -614,9 +616,18 @@ __device__ __forceinline__ void dense_role_mfma_wide(const void* __restrict__ xv
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   {
-    char __attribute__((address_space(3)))* base = reinterpret_cast<char __attribute__((address_space(3)))*>(wbase);
+    // entry (column c, index) lives at [c % 4][index][slot c / 4, and again at slot 16 + c / 4] (see the header)
+    const uint32_t ebase = wbase + (uint32_t)(lane & 3) * (uint32_t)(L * 256) + 8u * (uint32_t)(lane >> 2);
 #pragma unroll
-    for (int i = 0; i < NST; ++i) *reinterpret_cast<u32x2 __attribute__((address_space(3)))*>(base + 8 * (lane + 64 * i)) = split_entry(ev[i]);
+    for (int i = 0; i < NLV; ++i) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const u32x2 en = split_entry(lv[i][t]);
+        typedef u32x2 __attribute__((address_space(3))) lds_u32x2;
+        *reinterpret_cast<lds_u32x2*>(ebase + 256u * (uint32_t)(4 * i + t)) = en;
+        *reinterpret_cast<lds_u32x2*>(ebase + 256u * (uint32_t)(4 * i + t) + 128u) = en;
+      }
+    }
   }
   f32x4 acc[MB][4];
 #pragma unroll

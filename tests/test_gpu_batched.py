@@ -138,6 +138,39 @@ def test_wide_form_whole_rounds(qc, gpu, bits, cus):
     assert H.rel_err(got, H.oracle_ref(case, x, mul, "dense")) <= TOL_FP64
 
 
+@pytest.mark.parametrize("scratch_in_capture", [1, 0])
+def test_wide_form_in_a_captured_graph(gpu, scratch_in_capture):
+    """A wide-form hybrid op captured into a graph and replayed twice.  With scratch_in_capture = 1 the graph carries the
+    group's scratch block as an allocation and a free node around the transpose / split / sparse / dense / reduce launches;
+    with 0 it is allocation-free: the CSR role gathers from vec, the wide form (forced here) splits vec in registers and
+    its K slices add atomically."""
+    import torch
+
+    from squeezellm_amd import _lib, decode
+
+    K, N, batch = 1024, 1092, 130
+    case = H.make_case(4, K, N, sparse=0.02, topX=3, heavy_rows=1, seed=5)
+    lay = dict(H.to_torch(case, gpu), K=K, N=N, bits=4)
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(batch, K)).astype(np.float16).astype(np.float32)
+    mul = rng.normal(0, 0.5, size=(batch, N)).astype(np.float32)
+    xt, y0 = torch.from_numpy(x).to(gpu), torch.from_numpy(mul).to(gpu)
+    yt = y0.clone()
+    try:
+        _lib.set_option("mfma_wide_min_batch", 17)
+        _lib.set_option("scratch_in_capture", scratch_in_capture)
+        seq = decode.OpSequence([lay], [xt], [yt], batched=True)
+        g = seq.graph(warmup=1)
+        for _ in range(2):
+            yt.copy_(y0)
+            g.replay()
+            torch.cuda.synchronize()
+            assert H.rel_err(yt.cpu().numpy(), H.oracle_ref(case, x, mul, "hybrid")) <= TOL_FP64
+    finally:
+        _lib.set_option("mfma_wide_min_batch", 0)
+        _lib.set_option("scratch_in_capture", 1)
+
+
 def _routing(mfma_min, cols_min, cols_max):
     from squeezellm_amd import _lib
 
