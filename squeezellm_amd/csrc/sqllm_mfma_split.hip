@@ -412,6 +412,43 @@ __device__ __forceinline__ void col_addrs(const u32x4 (&t)[Fmt<BITS>::kRows], in
   }
 }
 
+// ... the same one address at a time (i = 0..7, a constant once the caller's loops are unrolled): `pre` = the column's
+// words prepared by col_prep -- 4-bit {low nibbles | wmask, high nibbles | wmask}, 3-bit the unit's three words
+template <int BITS>
+__device__ __forceinline__ void col_prep(const u32x4 (&t)[Fmt<BITS>::kRows], int J, uint32_t wmask, uint32_t (&pre)[3]) {
+  if constexpr (BITS == 4) {
+    const uint32_t w = t[0][J];
+    pre[0] = (w & 0x0F0F0F0Fu) | wmask;
+    pre[1] = ((w >> 4) & 0x0F0F0F0Fu) | wmask;
+    pre[2] = 0;
+  } else {
+    pre[0] = t[0][J]; pre[1] = t[1][J]; pre[2] = t[2][J];
+  }
+}
+template <int BITS, int PH>
+__device__ __forceinline__ uint32_t col_addr(const uint32_t (&pre)[3], int i, uint32_t lane_off) {
+  if constexpr (BITS == 4) {
+    const uint32_t src = pre[i & 1];
+    switch (i >> 1) {
+      case 0: return __builtin_amdgcn_perm(src, lane_off, 0x0C010400u);
+      case 1: return __builtin_amdgcn_perm(src, lane_off, 0x0C010500u);
+      case 2: return __builtin_amdgcn_perm(src, lane_off, 0x0C010600u);
+      default: return __builtin_amdgcn_perm(src, lane_off, 0x0C010700u);
+    }
+  } else {
+    switch (i) {
+      case 0: return lane_off | field3_x256<8 * PH + 0>(pre[0], pre[1], pre[2]);
+      case 1: return lane_off | field3_x256<8 * PH + 1>(pre[0], pre[1], pre[2]);
+      case 2: return lane_off | field3_x256<8 * PH + 2>(pre[0], pre[1], pre[2]);
+      case 3: return lane_off | field3_x256<8 * PH + 3>(pre[0], pre[1], pre[2]);
+      case 4: return lane_off | field3_x256<8 * PH + 4>(pre[0], pre[1], pre[2]);
+      case 5: return lane_off | field3_x256<8 * PH + 5>(pre[0], pre[1], pre[2]);
+      case 6: return lane_off | field3_x256<8 * PH + 6>(pre[0], pre[1], pre[2]);
+      default: return lane_off | field3_x256<8 * PH + 7>(pre[0], pre[1], pre[2]);
+    }
+  }
+}
+
 // packed B operand word k of 12 ({hi x 4, mid x 4, lo x 4}) out of the 8 looked-up entries
 __device__ __forceinline__ uint32_t pack_b(const u32x2 (&e)[8], int k) {
   const int i = k & 3, kind = k >> 2;
@@ -424,7 +461,7 @@ __device__ __forceinline__ uint32_t pack_b(const u32x2 (&e)[8], int k) {
 // alternates between looking a column up (addresses, 8 LDS reads, their latency, 12 packing instructions) and the 20-24
 // matrix instructions that use it -- with two waves per SIMD the matrix pipe was 65 % busy (profiles/r04_wide_pmc.txt).
 // Here the lookups of the NEXT column ride between the matrix instructions of the current one, slot by slot (a
-// scheduling barrier after each keeps the order): slot 0 its addresses, slots 2-5 two reads each, slots 8-19 one packing
+// scheduling barrier after each keeps the order): slot 0 its index words, slots 2-5 two addresses + reads each, slots 8-19 one packing
 // instruction each.  B enters holding the packed operands of (t, PH, column 0) and leaves holding those of
 // (tn, PHN, column 0), the first column of the phase that follows.
 template <int BITS, int XMODE, int PH, int PHN>
@@ -455,7 +492,7 @@ __device__ __forceinline__ void wide_phase(const u32x4 (&t)[Fmt<BITS>::kRows], c
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    uint32_t a[8], Bn[12];
+    uint32_t pre[3], Bn[12];
     u32x2 e[8];
     const uint32_t bh[4] = {B[0], B[1], B[2], B[3]}, bm[4] = {B[4], B[5], B[6], B[7]}, bl[4] = {B[8], B[9], B[10], B[11]};
     const bf16x8 Bh = as_frag(bh), Bm = as_frag(bm), Bl = as_frag(bl);
@@ -472,12 +509,15 @@ __device__ __forceinline__ void wide_phase(const u32x4 (&t)[Fmt<BITS>::kRows], c
         const bf16x8 Bx = (pp == 0 || pp == 3) ? Bm : pp == 1 ? Bl : Bh;
         acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bx, acc[mb][j], 0, 0, 0);
         if (slot == 0) {
-          if (j < 3) col_addrs<BITS, PH>(t, jn, lane_off, wmask, a);
-          else col_addrs<BITS, PHN>(tn, 0, lane_off, wmask, a);
+          if (j < 3) col_prep<BITS>(t, jn, wmask, pre);
+          else col_prep<BITS>(tn, 0, wmask, pre);
         }
-        if (slot >= 2 && slot < 6) {
-          e[2 * (slot - 2)] = lds_read_u32x2(a[2 * (slot - 2)] + jn * kColStride<BITS>);
-          e[2 * (slot - 2) + 1] = lds_read_u32x2(a[2 * (slot - 2) + 1] + jn * kColStride<BITS>);
+        if (slot >= 2 && slot < 6) {  // (addresses where they are used: eight of them alive at once cost the 3-bit kernel its last registers)
+#pragma unroll
+          for (int i = 2 * (slot - 2); i < 2 * (slot - 2) + 2; ++i) {
+            const uint32_t ad = j < 3 ? col_addr<BITS, PH>(pre, i, lane_off) : col_addr<BITS, PHN>(pre, i, lane_off);
+            e[i] = lds_read_u32x2(ad + jn * kColStride<BITS>);
+          }
         }
         if (slot >= 8 && slot < 20) {
           // (order: the words that need the earliest reads first -- pair 0's hi, mid, lo, then pair 1's ...)
@@ -640,34 +680,35 @@ __device__ __forceinline__ void dense_role_mfma_wide(const void* __restrict__ xv
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   // group g out of (w = its words, wn = the next group's, xcur = its phase-0 values); w is refilled with group g + 2's
-  // words once a copy is taken.  Loads return in order: the vec loads of the next phase go out BEFORE the far-ahead
+  // words once a copy is taken (4-bit) or the group is through (3-bit).  Loads return in order: the vec loads of the next phase go out BEFORE the far-ahead
   // weight load, so that waiting for them does not mean waiting for it.
   uint32_t Bst[12];  // packed B operands of the upcoming phase's first column (wide_phase)
   first_column<BITS, 0>(wa, lane_off, wmask, Bst);
   auto decode_group = [&](int g, u32x4 (&w)[R], const u32x4 (&wn)[R], u32x4 (&xcur)[NX], u32x4 (&xn)[NX], u32x4 (&xo)[NX]) {
-    u32x4 t[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) t[r] = w[r];
     const bool live = group_unit(g) < u_end;
     if constexpr (NPH == 1) {
+      u32x4 t[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) t[r] = w[r];
       load_x(g + 1, 0, xn);
       load_w(g + 2, w);
       __builtin_amdgcn_sched_barrier(0);
       wide_phase<BITS, XMODE, 0, 0>(t, wn, xcur, live, lane_off, wmask, Bst, acc);
     } else {
+      // (a group is four phases long: its words are refilled with group g + 2's once its last phase is through -- no copy)
       load_x(g, 1, xo);
-      load_w(g + 2, w);
       __builtin_amdgcn_sched_barrier(0);
-      wide_phase<BITS, XMODE, 0, 1>(t, t, xcur, live, lane_off, wmask, Bst, acc);
+      wide_phase<BITS, XMODE, 0, 1>(w, w, xcur, live, lane_off, wmask, Bst, acc);
       load_x(g, 2, xcur);
       __builtin_amdgcn_sched_barrier(0);
-      wide_phase<BITS, XMODE, 1, 2>(t, t, xo, live, lane_off, wmask, Bst, acc);
+      wide_phase<BITS, XMODE, 1, 2>(w, w, xo, live, lane_off, wmask, Bst, acc);
       load_x(g, 3, xo);
       __builtin_amdgcn_sched_barrier(0);
-      wide_phase<BITS, XMODE, 2, 3>(t, t, xcur, live, lane_off, wmask, Bst, acc);
+      wide_phase<BITS, XMODE, 2, 3>(w, w, xcur, live, lane_off, wmask, Bst, acc);
       load_x(g + 1, 0, xn);
       __builtin_amdgcn_sched_barrier(0);
-      wide_phase<BITS, XMODE, 3, 0>(t, wn, xo, live, lane_off, wmask, Bst, acc);
+      wide_phase<BITS, XMODE, 3, 0>(w, wn, xo, live, lane_off, wmask, Bst, acc);
+      load_w(g + 2, w);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
