@@ -20,14 +20,14 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_NAME = "libsqllm_hip.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
-SOURCES = ["sqllm_kernels.hip", "sqllm_mfma_split.hip", "sqllm_capi.hip"]
+SOURCES = ["sqllm_kernels.hip", "sqllm_mfma_split.hip", "sqllm_mfma_wide.hip", "sqllm_capi.hip"]
 # measured-and-not-adopted kernels (round 3: the streaming batch-1 kernel, the column-pair-table kernel; round 4: the
 # dependency-gated persistent pass) and the host code that routes to them: csrc/experimental/, part of the MEASUREMENT
 # library only (options "stream" / "pair4", entry points sqllm_pass_*)
 EXPERIMENTAL = os.path.join(CSRC, "experimental")
 EXPERIMENT_SOURCES = ["experimental/sqllm_ablation.hip", "experimental/sqllm_stream.hip", "experimental/sqllm_pair.hip",
                       "experimental/sqllm_pass.hip", "experimental/sqllm_experimental.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("sqllm_kernels.h", "sqllm_decode.h", "sqllm_roles.h", "sqllm_fused.h", "sqllm_host.h")] + [os.path.join(INCLUDE, "sqllm_hip.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("sqllm_kernels.h", "sqllm_decode.h", "sqllm_roles.h", "sqllm_fused.h", "sqllm_split_common.h", "sqllm_host.h")] + [os.path.join(INCLUDE, "sqllm_hip.h")]
 EXPERIMENT_HEADERS = [os.path.join(EXPERIMENTAL, h) for h in ("sqllm_pass.h", "sqllm_pass_api.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

@@ -202,7 +202,7 @@ void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch
   gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
 }
 
-// Geometry of the WIDE matrix-core kernel (sqllm_mfma_split.hip: sqllm_fused_wide).  A UNIT is a block of 64 rows x a
+// Geometry of the WIDE matrix-core kernel (sqllm_mfma_wide.hip: sqllm_fused_wide).  A UNIT is a block of 64 rows x a
 // group of 8 column tiles (one per wave).  Units are worked off one workgroup per CU at a time; as many whole rounds as
 // there are run every unit over ALL of K (no atomics, one table build); the units of the last, partial round are cut
 // into as many K slices as fill the idle CUs (their workgroups add atomically).  dense_blocks = workgroups of the 1-D
@@ -450,7 +450,7 @@ int64_t sqllm_linear_workspace_bytes(const sqllm_op* op) {
 // captures allocation-free).  ONE block per group holds
 //   xT     vec TRANSPOSED (xT[k][row]) for the CSR role: one coalesced read per non-zero serves every batch row instead
 //          of `batch` gathers 4 K bytes apart (only with a CSR term; option sparse_transpose);
-//   planes vec split once into bf16 planes in fragment order + the lo flags (sqllm_mfma_split.hip: sqllm_split_vec) for
+//   planes vec split once into bf16 planes in fragment order + the lo flags (sqllm_mfma_wide.hip: sqllm_split_vec) for
 //          the wide form (from split_planes_min_batch rows, default 64);
 //   slabs  the sums of the wide form's K slices (sqllm_wide_reduce adds them to mul).
 // Without scratch: the CSR role gathers from vec, the wide form splits in registers and its slices add atomically.

@@ -107,7 +107,7 @@ struct LaunchArgs {
   // wide-batch launches on the split matrix-core kernel: vec already split into bf16 planes (split_vec), or null
   const void* planes = nullptr;
   const uint32_t* plane_flags = nullptr;  // kSplitFlagWgs words: any non-zero lo part?
-  bool wide = false;  // the geometry is make_plan_wide's: workgroups of eight column tiles (sqllm_mfma_split.hip: sqllm_fused_wide)
+  bool wide = false;  // the geometry is make_plan_wide's: workgroups of eight column tiles (sqllm_mfma_wide.hip: sqllm_fused_wide)
   int wide_full_units = 0;  // ... and this many of them over all of K; the rest in gm.k_slices slices
   float* wide_slabs = nullptr;  // scratch for the slices' sums (wide_slab_bytes), or null: they add atomically
 };
@@ -155,6 +155,7 @@ hipError_t launch_stream(int bits, const StreamArgs& sa, const GroupArgs& ga, hi
                          int ablate);
 hipError_t launch_batched_mfma(int bits, const LaunchArgs& a, hipStream_t stream);        // fp32 matrix instructions
 hipError_t launch_batched_mfma_split(int bits, const LaunchArgs& a, hipStream_t stream);  // bf16 matrix instructions on exactly split operands (sqllm_mfma_split.hip)
+hipError_t launch_batched_mfma_wide(int bits, const LaunchArgs& a, hipStream_t stream);   // ... in the wide form (sqllm_mfma_wide.hip)
 hipError_t launch_batched_cols(int bits, const LaunchArgs& a, hipStream_t stream);
 constexpr int kSplitFlagWgs = 256;  // workgroups (and flag words) of split_vec
 // planes of split_vec, in 16-byte chunks: 3 planes x 64 lanes per (16 rows, 32 k's); rows padded to a multiple of 64, every

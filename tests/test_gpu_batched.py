@@ -85,7 +85,7 @@ def test_ppl_eval_batch_2048(qc, gpu, bits):
 @pytest.mark.parametrize("bits,K,N", [(4, 1024, 1092), (3, 1024, 776), (4, 4160, 516), (3, 2080, 1028), (4, 32, 4), (3, 32, 8)])
 @pytest.mark.parametrize("batch", [17, 64, 130, 700])
 def test_wide_form_vs_oracle(qc, gpu, vec, planes, bits, K, N, batch):
-    """The wide form of the split matrix-core kernel (csrc/sqllm_mfma_split.hip: sqllm_fused_wide; default from 512 rows),
+    """The wide form of the split matrix-core kernel (csrc/sqllm_mfma_wide.hip: sqllm_fused_wide; default once batch * K * N >= 5.7e9),
     forced from 17 rows up: workgroups of eight column tiles, vec from bf16 planes in fragment order (sqllm_split_vec) or --
     without scratch -- split in registers; fp16-born vec takes the five-product path (no lo plane), fp32 vec all six.
     Shapes: a last column group of one tile and 4 columns (1092), K that is not a whole number of 32-k steps times

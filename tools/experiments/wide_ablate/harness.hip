@@ -1,5 +1,5 @@
 // Standalone timing harness for the wide matrix-core kernel and text-patched ablations of it (tools/experiments/wide_ablate/run.sh
-// builds one binary per variant from a patched COPY of csrc/sqllm_mfma_split.hip: the product source carries no switches).
+// builds one binary per variant from a patched COPY of csrc/sqllm_mfma_wide.hip: the product source carries no switches).
 // 13B gate/up shape, 4-bit or 3-bit, 2048 rows, random operands; prints microseconds per launch.
 #include KERNEL_SOURCE
 #include <cstdio>

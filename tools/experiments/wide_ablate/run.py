@@ -2,7 +2,7 @@
 """Build (here, no GPU needed) or run (on the GPU box) the ablation binaries of the wide matrix-core kernel.
     python tools/experiments/wide_ablate/run.py build     # -> tools/experiments/wide_ablate/bin/<variant>
     python tools/experiments/wide_ablate/run.py run       # prints one line per variant and configuration
-Each variant is a text patch of a COPY of csrc/sqllm_mfma_split.hip."""
+Each variant is a text patch of a COPY of csrc/sqllm_mfma_wide.hip."""
 import os
 import subprocess
 import sys
@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
 CSRC = os.path.join(ROOT, "squeezellm_amd", "csrc")
-SRC = os.path.join(CSRC, "sqllm_mfma_split.hip")
+SRC = os.path.join(CSRC, "sqllm_mfma_wide.hip")
 BIN = os.path.join(HERE, "bin")
 
 LOADX_HEAD = "  auto load_x = [&](int g, int ph, u32x4 (&dx)[NX]) {\n    const int gu = group_unit(g);"
@@ -24,29 +24,25 @@ def patch(text, name):
         tail = tail.replace(LOADX_HEAD, LOADX_HEAD.replace("{\n", "{\n    if (g > 0 || ph > 0) return;\n", 1), 1)
     if "noW" in name:  # weights loaded for groups 0 and 1 only
         tail = tail.replace(LOADW_HEAD, LOADW_HEAD.replace("{\n", "{\n    if (g > 1) return;\n", 1), 1)
-    if "noLDS" in name:  # entries made up from the packed words instead of looked up
-        head = head.replace("      e[0] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C010400u) + off);",
-                            "      for (int i_ = 0; i_ < 8; ++i_) e[i_] = u32x2{lo + i_, hi ^ wmask};\n      if (lane_off == 0xFFFFFFFFu) e[0] = lds_read_u32x2(__builtin_amdgcn_perm(lo, lane_off, 0x0C010400u) + off);", 1)
-        for i in range(1, 8):
-            sel = ["lo", "hi"][i & 1]
-            old = f"      e[{i}] = lds_read_u32x2(__builtin_amdgcn_perm({sel}, lane_off, 0x0C010{4 + i // 2}00u) + off);\n"
-            assert old in head, old
-            head = head.replace(old, "", 1)
+    if "noLDS" in name:  # entries made up from the addresses instead of looked up
+        old = "            e[i] = lds_read_u32x2(ad + jn * kColStride<BITS>);"
+        assert old in head + tail
+        head, tail = head.replace(old, "            e[i] = u32x2{ad, ad ^ wmask};", 1), tail.replace(old, "            e[i] = u32x2{ad, ad ^ wmask};", 1)
     if "halfMFMA" in name:  # three of the partial products dropped
-        for op in ("Am, Bm", "Ah, Bl", "Ah, Bm"):
-            old = f"c = __builtin_amdgcn_mfma_f32_16x16x32_bf16({op}, c, 0, 0, 0);"
-            assert old in head
-            head = head.replace(old, "", 1)
+        old = "        acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bx, acc[mb][j], 0, 0, 0);"
+        assert old in head + tail
+        new_ = "        if (pp == 2 || pp >= 4) acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bx, acc[mb][j], 0, 0, 0);"
+        head, tail = head.replace(old, new_, 1), tail.replace(old, new_, 1)
     if "noLut" in name:  # codebook values made up instead of gathered
-        old = "    ev[i] = lut[(size_t)c * L + (row % L)];"
+        old = "    for (int i = 0; i < NLV; ++i) lv[i] = lp[i];"
         assert old in tail
-        tail = tail.replace(old, "    ev[i] = 1e-3f * (float)(c + row);", 1)
+        tail = tail.replace(old, "    for (int i = 0; i < NLV; ++i) lv[i] = f32x4{1e-3f * c, 2e-3f * i, 3e-3f, 4e-3f}; (void)lp;", 1)
     if "noEpi" in name:
         tail = tail.replace("  if (c0 < N) {  // (N is a multiple of 4", "  if (c0 < N && batch < 0) {  // (N is a multiple of 4", 1)
     return head + tail
 
 
-VARIANTS = ["base", "noEpi", "noLut", "noEpi_noLut", "noA_noW_noLDS_noEpi_noLut"]
+VARIANTS = ["base", "noA", "noW", "noLDS", "noEpi", "noLut", "halfMFMA", "noA_noW_noLDS_noEpi_noLut"]
 
 
 def build():
