@@ -30,7 +30,8 @@ constexpr int kWaves = SQLLM_WAVES;          // waves per workgroup (512 threads
 constexpr int kTileN = 64;         // output columns per dense tile = 16 lanes x 4 (one dwordx4 each)
 constexpr int kCsrChunk = SQLLM_CSR_CHUNK;  // non-zeros per CSR workgroup (a multiple of 1024: a lane holds a run of 2+)
 constexpr int kCsrSpanMax = 2048;  // CSR rows a chunk may span and still accumulate in LDS
-constexpr int kCsrXtSpan = 191;    // ... and still keep a 64-row tile of sums in LDS (wide batches, transposed vec)
+constexpr int kCsrXtSpan = 191;    // ... and still keep a 64-row tile of sums in LDS (wide batches, transposed vec; half of it: a 128-row tile)
+constexpr int kSparsePassRows = 128;  // batch rows per workgroup of the wide-batch sparse launch
 constexpr int kTopxRows = SQLLM_TOPX_ROWS;  // k's per top-X slab (a multiple of 32)
 constexpr int kTopxLds = 1024;     // topX up to which slab sums are kept in LDS
 constexpr int kMaxBatchTile = 8;   // batch rows handled per weight pass

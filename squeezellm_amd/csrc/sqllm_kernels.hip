@@ -353,7 +353,7 @@ sqllm_fused_batched(const float* x, const GroupArgs ga) {
 // The sparse terms of a wide-batch op, as a launch of their own: inside the matrix-core kernel the
 // CSR workgroups would inherit its register allocation (one or two workgroups per CU) and run their
 // latency-bound loops without anybody to hide behind -- measured 3.3 ms of a 5.7 ms launch at
-// 2048 rows.  Passes of 64 rows (blockIdx.y); blockIdx.x = CSR chunks, then top-X slabs.
+// 2048 rows.  Blocks of kSparsePassRows = 128 rows (blockIdx.y); blockIdx.x = CSR chunks, then top-X slabs.
 //   xT != null: the CSR role reads the transposed copy of vec (lane = batch row);
 //   xT == null (no scratch, or the stream is capturing): it gathers from vec, 32 rows at a time.
 template <int WAVES>
@@ -366,9 +366,11 @@ sqllm_sparse_batched(const float* x, const GroupArgs ga, const float* xT, int Bp
   __builtin_amdgcn_sched_barrier(0);
   const KernelGeom& gm = sg.gm;
   const int sp = blockIdx.x;
-  const int m0 = blockIdx.y * 64;
+  // blockIdx.y = a block of kSparsePassRows rows: the CSR role with a transposed vec takes them two per lane where it can
+  // (csr_role), everything else in passes of 64 / 32
+  const int m0 = blockIdx.y * kSparsePassRows;
   int rows_here = gm.batch - m0;
-  if (rows_here > 64) rows_here = 64;
+  if (rows_here > kSparsePassRows) rows_here = kSparsePassRows;
   if (sp < gm.csr_blocks) {
     if (xT) {
       csr_role<T, 1, float, float, true>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, m0, rows_here, sp, lds, nullptr, 0, xT, Bp
@@ -386,7 +388,11 @@ sqllm_sparse_batched(const float* x, const GroupArgs ga, const float* xT, int Bp
       }
     }
   } else if (sp < gm.csr_blocks + gm.topx_blocks) {
-    topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, m0, rows_here, sp - gm.csr_blocks, lds);
+    for (int bb = 0; bb < rows_here; bb += 64) {
+      if (bb) __syncthreads();
+      topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, m0 + bb, rows_here - bb < 64 ? rows_here - bb : 64,
+                                 sp - gm.csr_blocks, lds);
+    }
   }
 }
 
@@ -748,7 +754,7 @@ hipError_t launch_batched_cols(int bits, const LaunchArgs& a, hipStream_t stream
 hipError_t launch_batched_sparse(const LaunchArgs& a, hipStream_t stream) {
   const KernelGeom& gm = a.ga.seg[0].gm;
   if (gm.csr_blocks + gm.topx_blocks <= 0) return hipSuccess;
-  dim3 grid(gm.csr_blocks + gm.topx_blocks, (gm.batch + 63) / 64);
+  dim3 grid(gm.csr_blocks + gm.topx_blocks, (gm.batch + kSparsePassRows - 1) / kSparsePassRows);
   auto kern = sqllm_sparse_batched<kWaves>;
   const float* x = static_cast<const float*>(a.x);
   if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga, a.xT, a.Bp);

@@ -154,7 +154,10 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
   const bool use_tile = XTMODE && in_lds && n <= kCsrXtSpan;
   const int TS = n | 1;
   float* tile = lds + kCsrSpanMax;
-  if (use_tile) for (int i = tid; i < (nb <= 16 ? 16 : nb <= 32 ? 32 : 64) * TS; i += T) tile[i] = 0.f;  // (the rows of this pass's lane groups)
+  // (passes of up to 128 rows, two per lane, where a 128-row tile fits -- a chunk spanning at most kCsrXtSpan / 2 rows;
+  // otherwise 64 rows at a time)
+  const bool two_rows = use_tile && nb > 64 && n <= kCsrXtSpan / 2;
+  if (use_tile) for (int i = tid; i < (nb <= 16 ? 16 : nb <= 32 ? 32 : two_rows ? 128 : 64) * TS; i += T) tile[i] = 0.f;  // (the rows of this pass's lane groups)
   __syncthreads();
   SQLLM_CSR_STAMP(2)  // row pointers staged
 
@@ -207,76 +210,134 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
     constexpr int WN = 64 * EPT;  // non-zeros per wave
     const int lane = tid & 63;
     int* st = reinterpret_cast<int*>(lds + kCsrSpanMax + 64 * (kCsrXtSpan + 1)) + (tid >> 6) * WN;  // [3][kCsrChunk]
-    if (nb <= 32 && use_tile) {
-#pragma unroll
-      for (int i = 0; i < EPT; ++i) {
-        st[64 * i + lane] = col[i];
-        st[kCsrChunk + 64 * i + lane] = lr[i] >= 0 ? __builtin_bit_cast(int, val[i]) : 0;
-        st[2 * kCsrChunk + 64 * i + lane] = lr[i];
-      }
-    }
     float* yf = reinterpret_cast<float*>(y);
-    if (nb <= 16 && use_tile) xt_walk<16, WN>(st, xT, Bp, b0, nb, tile, TS, lane);
-    else if (nb <= 32 && use_tile) xt_walk<32, WN>(st, xT, Bp, b0, nb, tile, TS, lane);
-    else {
-      // 33-64 rows (or a chunk spanning too many rows for the tile): one group, every lane a batch row.  Column, value and row come out of the owning lane with
-      // v_readlane, so control flow and addresses are scalar (2 % faster at 2048 rows than the walk through LDS).
-      const bool row_ok = lane < nb;
-      const float* xl = xT + (b0 + (row_ok ? lane : 0));
-      unsigned long long ends[EPT], valid[EPT];
-      int n_valid = 0;
+    // what the one-group walks need, the same for every pass: where rows end, which lanes hold a non-zero
+    unsigned long long ends[EPT], valid[EPT];
+    int n_valid = 0;
 #pragma unroll
-      for (int i = 0; i < EPT; ++i) {
-        const int above = dpp_i32<0x130, 0xf>(lr[i], -2);  // the lane above's row (lane 63: none)
-        ends[i] = __ballot(above != lr[i] && lr[i] >= 0);
-        valid[i] = __ballot(lr[i] >= 0);
-        n_valid += __builtin_popcountll(valid[i]);
+    for (int i = 0; i < EPT; ++i) {
+      const int above = dpp_i32<0x130, 0xf>(lr[i], -2);  // the lane above's row (lane 63: none)
+      ends[i] = __ballot(above != lr[i] && lr[i] >= 0);
+      valid[i] = __ballot(lr[i] >= 0);
+      n_valid += __builtin_popcountll(valid[i]);
+    }
+#pragma unroll
+    for (int i = 0; i + 1 < EPT; ++i)  // a row that runs on into the next run keeps its sum in the register
+      if ((valid[i + 1] & 1ull) && __builtin_amdgcn_readlane(lr[i], 63) == __builtin_amdgcn_readlane(lr[i + 1], 0)) ends[i] &= ~(1ull << 63);
+    // The rows this workgroup was given (sqllm_sparse_batched: up to 128) go through in passes of `step`; the chunk's
+    // columns, values and row searches above are paid once.
+    const int step = two_rows ? 128 : 64;
+    bool staged = false;
+    for (int pb = 0; pb < nb; pb += step) {
+      const int nbp = nb - pb < step ? nb - pb : step;
+      const int bp0 = b0 + pb;
+      if (pb) {  // the tile again (the previous pass's flush has read it)
+        __syncthreads();
+        if (use_tile) for (int i = tid; i < 64 * TS; i += T) tile[i] = 0.f;
+        __syncthreads();
       }
+      if (nbp <= 32 && use_tile && !staged) {
 #pragma unroll
-      for (int i = 0; i + 1 < EPT; ++i)  // a row that runs on into the next run keeps its sum in the register
-        if ((valid[i + 1] & 1ull) && __builtin_amdgcn_readlane(lr[i], 63) == __builtin_amdgcn_readlane(lr[i + 1], 0)) ends[i] &= ~(1ull << 63);
-      float acc = 0.f;
-      bool first_seg = true;
+        for (int i = 0; i < EPT; ++i) {
+          st[64 * i + lane] = col[i];
+          st[kCsrChunk + 64 * i + lane] = lr[i] >= 0 ? __builtin_bit_cast(int, val[i]) : 0;
+          st[2 * kCsrChunk + 64 * i + lane] = lr[i];
+        }
+        staged = true;
+      }
+      if (nbp <= 16 && use_tile) xt_walk<16, WN>(st, xT, Bp, bp0, nbp, tile, TS, lane);
+      else if (nbp <= 32 && use_tile) xt_walk<32, WN>(st, xT, Bp, bp0, nbp, tile, TS, lane);
+      else if (nbp > 64) {
+        // 65-128 rows, TWO per lane (rows 2 lane, 2 lane + 1: one 8-byte read per non-zero): the walk is bound by its
+        // per-non-zero instructions -- a scalar chain from v_readlane to the load's address -- not by bytes (reading
+        // half-width values changed nothing: 412 vs 426 us per 13B gate/up op at 2048 rows), so each step now serves
+        // twice the rows.
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const int r0 = 2 * lane;
+        const float* xl = xT + (bp0 + (r0 < nbp ? r0 : 0));  // (rows past the pass: the first pair again; never stored)
+        float acc0 = 0.f, acc1 = 0.f;
+        bool first_seg = true;
 #pragma unroll
-      for (int i = 0; i < EPT; ++i) {
-        constexpr int U = 32;  // loads in flight per wave: the role is latency-bound (a chunk is 1-2 workgroups per CU)
-        for (int j0 = 0; j0 < 64; j0 += U) {
-          if (((valid[i] >> j0) & 1ull) == 0) break;  // (valid lanes are a prefix)
-          float xv[U];
+        for (int i = 0; i < EPT; ++i) {
+          constexpr int U = 32;
+          for (int j0 = 0; j0 < 64; j0 += U) {
+            if (((valid[i] >> j0) & 1ull) == 0) break;  // (valid lanes are a prefix)
+            f32x2_t xv[U];
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int k = __builtin_amdgcn_readlane(col[i], j0 + u);
-            xv[u] = xl[(size_t)k * Bp];
-          }
+            for (int u = 0; u < U; ++u) {
+              const int k = __builtin_amdgcn_readlane(col[i], j0 + u);
+              xv[u] = *reinterpret_cast<const f32x2_t*>(xl + (size_t)k * Bp);
+            }
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int j = j0 + u;
-            const float v = ((valid[i] >> j) & 1ull) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val[i]), j)) : 0.f;
-            acc = __builtin_fmaf(v, xv[u], acc);
-            if ((ends[i] >> j) & 1ull) {
-              const int r = __builtin_amdgcn_readlane(lr[i], j);
-              if (use_tile) {
-                float* slot = tile + lane * TS + r;
-                if (first_seg || 64 * i + j == n_valid - 1) atomicAdd(slot, acc);  // the wave's first and last row: shared with its neighbours
-                else *slot = acc;
-              } else if (row_ok) {
-                acc_add(yf + (size_t)(b0 + lane) * N + c_lo + r, acc);
+            for (int u = 0; u < U; ++u) {
+              const int j = j0 + u;
+              const float v = ((valid[i] >> j) & 1ull) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val[i]), j)) : 0.f;
+              acc0 = __builtin_fmaf(v, xv[u].x, acc0);
+              acc1 = __builtin_fmaf(v, xv[u].y, acc1);
+              if ((ends[i] >> j) & 1ull) {
+                const int r = __builtin_amdgcn_readlane(lr[i], j);
+                float* slot = tile + r0 * TS + r;
+                if (first_seg || 64 * i + j == n_valid - 1) {  // the wave's first and last row: shared with its neighbours
+                  atomicAdd(slot, acc0);
+                  atomicAdd(slot + TS, acc1);
+                } else {
+                  slot[0] = acc0;
+                  slot[TS] = acc1;
+                }
+                first_seg = false;
+                acc0 = acc1 = 0.f;
               }
-              first_seg = false;
-              acc = 0.f;
+            }
+          }
+        }
+      } else {
+        // 33-64 rows (or a chunk spanning too many rows for the tile): one group, every lane a batch row.  Column, value and row come out of the owning lane with
+        // v_readlane, so control flow and addresses are scalar (2 % faster at 2048 rows than the walk through LDS).
+        const bool row_ok = lane < nbp;
+        const float* xl = xT + (bp0 + (row_ok ? lane : 0));
+        float acc = 0.f;
+        bool first_seg = true;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+          constexpr int U = 32;  // loads in flight per wave: the role is latency-bound (a chunk is 1-2 workgroups per CU)
+          for (int j0 = 0; j0 < 64; j0 += U) {
+            if (((valid[i] >> j0) & 1ull) == 0) break;  // (valid lanes are a prefix)
+            float xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int k = __builtin_amdgcn_readlane(col[i], j0 + u);
+              xv[u] = xl[(size_t)k * Bp];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int j = j0 + u;
+              const float v = ((valid[i] >> j) & 1ull) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val[i]), j)) : 0.f;
+              acc = __builtin_fmaf(v, xv[u], acc);
+              if ((ends[i] >> j) & 1ull) {
+                const int r = __builtin_amdgcn_readlane(lr[i], j);
+                if (use_tile) {
+                  float* slot = tile + lane * TS + r;
+                  if (first_seg || 64 * i + j == n_valid - 1) atomicAdd(slot, acc);  // the wave's first and last row: shared with its neighbours
+                  else *slot = acc;
+                } else if (row_ok) {
+                  acc_add(yf + (size_t)(bp0 + lane) * N + c_lo + r, acc);
+                }
+                first_seg = false;
+                acc = 0.f;
+              }
             }
           }
         }
       }
-    }
-    SQLLM_CSR_STAMP(4)  // this wave's non-zeros walked
-    if (use_tile) {
-      __syncthreads();
-      const int nm1 = n - 1;
-      for (int idx = tid; idx < nm1 * nb; idx += T) {
-        const int b = idx / nm1, r = idx - b * nm1;
-        const float sum = tile[b * TS + r];
-        if (sum != 0.f) acc_add(reinterpret_cast<float*>(y) + (size_t)(b0 + b) * N + c_lo + r, sum);
+      SQLLM_CSR_STAMP(4)  // this wave's non-zeros walked
+      if (use_tile) {
+        __syncthreads();
+        const int nm1 = n - 1;
+        for (int idx = tid; idx < nm1 * nbp; idx += T) {
+          const int b = idx / nm1, r = idx - b * nm1;
+          const float sum = tile[b * TS + r];
+          if (sum != 0.f) acc_add(reinterpret_cast<float*>(y) + (size_t)(bp0 + b) * N + c_lo + r, sum);
+        }
       }
     }
     SQLLM_CSR_STAMP(5)  // atomics issued
