@@ -42,15 +42,16 @@ int main(int argc, char** argv) {
   gm.col_tiles = (N + 63) / 64;
   gm.units_total = bits == 4 ? K / 8 : K / 32;
   // k_slices > 0: every unit in that many slices (the old 2-D plan); 0: the product's plan -- whole rounds over all of K, the last round sliced
-  const int col_groups = (gm.col_tiles + 7) / 8, row_blocks = (batch + 63) / 64;
+  const int col_groups = (gm.col_tiles + WT - 1) / WT, row_blocks = (batch + 63) / 64;
+  const int slots = 256 * (8 / WT);  // workgroups resident at once
   const int units = col_groups * row_blocks;
   int full = 0;
   if (k_slices > 0) {
     gm.units_per_wg = ((gm.units_total + k_slices - 1) / k_slices + 3) / 4 * 4;
   } else {
-    full = units / 256 * 256;
+    full = units / slots * slots;
     const int rem = units - full;
-    const int sl = rem ? 256 / rem : 1;
+    const int sl = rem ? slots / rem : 1;
     gm.units_per_wg = ((gm.units_total + sl - 1) / sl + 3) / 4 * 4;
   }
   gm.k_slices = (gm.units_total + gm.units_per_wg - 1) / gm.units_per_wg;
@@ -61,8 +62,8 @@ int main(int argc, char** argv) {
   float best = 1e30f;
   for (int rep = 0; rep < 4; ++rep) {
     CK(hipEventRecord(e0, 0));
-    if (bits == 4) hipLaunchKernelGGL((sqllm::sqllm_fused_wide<4, true>), grid, dim3(512), 0, 0, (const void*)dp, (const uint32_t*)df, full, (float*)nullptr, ga);
-    else hipLaunchKernelGGL((sqllm::sqllm_fused_wide<3, true>), grid, dim3(512), 0, 0, (const void*)dp, (const uint32_t*)df, full, (float*)nullptr, ga);
+    if (bits == 4) hipLaunchKernelGGL((sqllm::sqllm_fused_wide<4, true>), grid, dim3(WT * 64), 0, 0, (const void*)dp, (const uint32_t*)df, full, (float*)nullptr, ga);
+    else hipLaunchKernelGGL((sqllm::sqllm_fused_wide<3, true>), grid, dim3(WT * 64), 0, 0, (const void*)dp, (const uint32_t*)df, full, (float*)nullptr, ga);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));

@@ -37,12 +37,18 @@ def patch(text, name):
         old = "    for (int i = 0; i < NLV; ++i) lv[i] = lp[i];"
         assert old in tail
         tail = tail.replace(old, "    for (int i = 0; i < NLV; ++i) lv[i] = f32x4{1e-3f * c, 2e-3f * i, 3e-3f, 4e-3f}; (void)lp;", 1)
+    if "wt4" in name:  # four column tiles (waves) per workgroup, two workgroups per CU
+        for old, new in (("constexpr int kWideTiles = 8;", "constexpr int kWideTiles = 4;"),
+                         ("__global__ void __launch_bounds__(kWaves * 64, 2)\nsqllm_fused_wide", "__global__ void __launch_bounds__(kWideTiles * 64, 2)\nsqllm_fused_wide"),
+                         ('  static_assert(kWaves == kWideTiles, "one column tile per wave");\n', "")):
+            assert old in head + tail, old
+            head, tail = head.replace(old, new, 1), tail.replace(old, new, 1)
     if "noEpi" in name:
         tail = tail.replace("  if (c0 < N) {  // (N is a multiple of 4", "  if (c0 < N && batch < 0) {  // (N is a multiple of 4", 1)
     return head + tail
 
 
-VARIANTS = ["base", "noA", "noW", "noLDS", "noEpi", "noLut", "halfMFMA", "noA_noW_noLDS_noEpi_noLut"]
+VARIANTS = ["base", "wt4"]
 
 
 def build():
@@ -52,14 +58,14 @@ def build():
         src = os.path.join(BIN, f"kernel_{v}.hip")
         open(src, "w").write(patch(text, v))
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fno-gpu-rdc", f"-I{ROOT}/include", f"-I{CSRC}",
-               f'-DKERNEL_SOURCE="{src}"', f'-DVARIANT="{v}"', os.path.join(HERE, "harness.hip"), "-o", os.path.join(BIN, v)]
+               f'-DKERNEL_SOURCE="{src}"', f'-DVARIANT="{v}"', f'-DWT={4 if "wt4" in v else 8}', os.path.join(HERE, "harness.hip"), "-o", os.path.join(BIN, v)]
         subprocess.check_call(cmd)
         os.remove(src)
         print("built", v, flush=True)
 
 
 def run():
-    for args in (["4", "128", "0", "0"], ["4", "256", "0", "0"], ["4", "128", "0", "2"], ["4", "2048", "0", "0"]):
+    for args in (["4", "128", "0", "0"], ["4", "256", "0", "0"], ["4", "512", "0", "0"], ["4", "2048", "0", "0"], ["4", "2048", "1", "0"], ["3", "2048", "0", "0"]):
         for v in VARIANTS:
             subprocess.call([os.path.join(BIN, v)] + args)
         print(flush=True)
