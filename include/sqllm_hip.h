@@ -256,9 +256,9 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *   "mfma_min_batch", "cols_min_batch", "cols_max_batch"
  *                     routing of the *_batched operators by batch size: cols_min_batch .. cols_max_batch
  *                     rows run on the column-lane kernel (lane = output column, vec in SGPRs),
- *                     mfma_min_batch rows and more on the fp32 matrix cores, everything else on the
+ *                     mfma_min_batch rows and more on the matrix cores, everything else on the
  *                     batch tiles of the batch-1 kernel.  Defaults (value 0 = measured default, which
- *                     depends on the bit width; get_option returns the stored 0): 4-bit 2..4 / 9, 3-bit 2..8 / 9.
+ *                     depends on the bit width; get_option returns the stored 0): 4-bit 2..4 / 5, 3-bit 2..8 / 9.
  *                     With the two cols_* options at their defaults the column-lane kernel is further reserved
  *                     for what it measured faster on: 4-bit, groups of three or more ops and single ops of
  *                     >= 20 MB packed weights; 3-bit, >= 16 MB at up to 4 rows or N >= 8192; setting either option

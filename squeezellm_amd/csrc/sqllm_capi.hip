@@ -257,7 +257,11 @@ bool takes_wide_path(const sqllm_op* op, bool with_scratch, bool capturing) {
 
 int mfma_min_batch_of(const sqllm_op* op) {
   const int v = knobs().mfma_min_batch.load(std::memory_order_relaxed);
-  return v > 0 ? v : 9;  // (3-bit: 17 until round 4 -- from 9 rows the fused small-batch launch of the split matrix-core kernel beats the column-lane kernel: 13B s45 layer 191-226 vs 270-286 us at 9-16 rows)
+  // 3-bit: 17 until round 4 -- from 9 rows the fused small-batch launch of the split matrix-core kernel beats the
+  // column-lane kernel (13B s45 layer 191-226 vs 270-286 us at 9-16 rows).  4-bit: from 5 rows it beats the batch tiles
+  // once its CSR role runs an 8-row tile (131 / 135 / 142 vs 143 / 146 / 153 us at 5 / 6 / 8 rows; at 3 bits it loses
+  // there, 162-177 vs 130-150: profiles/r04_small_batch_layer_min5.txt)
+  return v > 0 ? v : (op->bits == 4 ? 5 : 9);
 }
 int cols_max_batch_of(const sqllm_op* op) {
   const int v = knobs().cols_max_batch.load(std::memory_order_relaxed);

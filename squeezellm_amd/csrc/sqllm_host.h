@@ -22,7 +22,7 @@ struct Knobs {
   std::atomic<int> cols_groups{1};  // 0: a group of ops never takes the column-lane kernel (as before round 3)
   // Routing of the *_batched operators by batch size (0 = the measured defaults, which depend on the bit width:
   // 13B gate/up shape, profiles/r02_batch_paths_*.txt):
-  //   4-bit: 2..4 rows column-lane kernel, 5..8 batch tiles of the batch-1 kernel, 9+ matrix cores
+  //   4-bit: 2..4 rows column-lane kernel (or batch tiles: cols_pays), 5+ matrix cores (round 4; before: 5..8 batch tiles)
   //   3-bit: 2..8 rows column-lane kernel, 9+ matrix cores
   std::atomic<int> mfma_min_batch{0};  // rows from which the matrix-core kernel takes over
   std::atomic<int> cols_min_batch{0};  // the column-lane kernel serves cols_min_batch .. cols_max_batch rows (0 = default: 2)

@@ -277,7 +277,8 @@ sqllm_fused_small_split(const float* x, const GroupArgs ga, const float* xT, int
     // vec transposed (xT[k][row], written by sqllm_transpose_vec just before this launch): ONE 64-byte read per non-zero
     // serves all the rows; without scratch, gathers from vec itself, one per non-zero and row
     if (xT) csr_role<T, 1, float, float, true>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, 0, gm.batch, bid, lds, nullptr, 0, xT, Bp);
-    else csr_role<T, kSmallRows, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, 0, gm.batch, bid, lds, nullptr, 0);
+    else if (gm.batch > 8) csr_role<T, kSmallRows, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, 0, gm.batch, bid, lds, nullptr, 0);
+    else csr_role<T, 8, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, 0, gm.batch, bid, lds, nullptr, 0);  // (the role gathers and loops for its full tile of rows)
   } else if (bid < gm.csr_blocks + gm.topx_blocks) {
     topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, 0, gm.batch, bid - gm.csr_blocks, lds);
   }

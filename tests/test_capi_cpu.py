@@ -92,8 +92,8 @@ def test_plan_geometry():
     _lib.set_option("cols_min_batch", 1 << 30)  # switched off: the batch tiles of the batch-1 kernel
     assert _lib.plan_query(3, 5120, 13824, batch=4)["dense_blocks"] == pc["col_tiles"] * _lib.plan_query(3, 5120, 13824, batch=4)["k_slices"]
     _lib.set_option("cols_min_batch", 0)
-    # batches from `mfma_min_batch` (9) rows up take the matrix-core kernel: passes of 16 / 32 / 64 rows
-    assert _lib.get_option("mfma_min_batch") == 0  # = the measured default: 9 rows
+    # batches from `mfma_min_batch` (4-bit 5, 3-bit 9) rows up take the matrix-core kernel: passes of 16 / 32 / 64 rows
+    assert _lib.get_option("mfma_min_batch") == 0  # = the measured default: 5 rows at 4 bits, 9 at 3
     assert _lib.plan_query(4, 4096, 4096, batch=8)["grid_y"] == 1 and _lib.plan_query(3, 4096, 4096, batch=16)["grid_y"] == 1  # (3-bit: matrix cores from 9 rows since round 4)
     assert _lib.plan_query(3, 4096, 4096, batch=17)["grid_y"] == 1
     assert _lib.plan_query(4, 4096, 4096, batch=9)["grid_y"] == 1
