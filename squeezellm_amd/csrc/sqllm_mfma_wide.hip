@@ -199,7 +199,8 @@ __device__ __forceinline__ void first_column(const u32x4 (&t)[Fmt<BITS>::kRows],
 // per wave, codebook table private to the wave, 16 KB (4-bit) / 8 KB (3-bit) of LDS each -- and every wave walks the
 // SAME k's: the A fragments of a step are fetched from the L2 once per workgroup and found in the CU's vector cache by
 // the other seven waves (eight times less vec traffic), no cross-wave sum, no barrier anywhere in the kernel; a wave
-// adds its 64 x 64 results straight to mul.  Grid: x = (group of 8 column tiles, K slice), y = block of 64 rows.
+// adds its 64 x 64 results straight to mul (or, as a K slice, leaves them as a slab for sqllm_wide_reduce).  Grid and
+// work units: see sqllm_fused_wide.
 // ------------------------------------------------------------------------------------------------
 constexpr int kWideTiles = 8;  // column tiles per workgroup = waves
 constexpr int kWideSlabFloats = 64 * kTileN;  // a wave's 64 x 64 sums
