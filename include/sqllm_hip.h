@@ -271,9 +271,9 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     The scratch is stream-ordered (hipMallocAsync / hipFreeAsync on the caller's
  *                     stream, K x ceil64(batch) floats per op or group); on first use per device the
  *                     library raises the release threshold of the device's DEFAULT memory pool to
- *                     256 MiB (never lowers it) so that the block survives synchronisations.
+ *                     1 GiB (never lowers it) so that the block survives synchronisations.
  *   "scratch_pool_threshold" 1 (default): on first use of that scratch per device the library raises the release threshold of
- *                     the device's DEFAULT memory pool to 256 MiB (process-wide state, never lowered); 0: it leaves the pool alone
+ *                     the device's DEFAULT memory pool to 1 GiB (process-wide state, never lowered); 0: it leaves the pool alone
  *                     (every synchronisation may then hand the scratch back to the OS)
  *   "scratch_in_capture" 1 (default): that scratch is also taken while the stream is capturing --
  *                     a captured wide-batch op with a CSR term then carries a memory-allocation

@@ -29,10 +29,10 @@ int device_slot() {
 
 Knobs& knobs() { return g_knobs[device_slot()]; }
 
-// The wide-batch CSR path takes stream-ordered scratch (hipMallocAsync) per op.  The default pool's
+// The wide-batch paths take stream-ordered scratch (hipMallocAsync) per group of ops.  The default pool's
 // release threshold is 0: every synchronisation hands the block back to the OS and the next call pays
 // a real allocation + map.  Raise it once per device (never lower it) so that the pool keeps what one
-// op needs (2048 rows x K = 22016 floats is 180 MB).
+// group needs (2048 rows x K = 22016: transposed vec 180 MB + bf16 planes 271 MB + slabs <= 32 MB).
 static void keep_scratch_in_pool() {
   static std::atomic<unsigned> done{0};
   if (!knobs().scratch_pool_threshold.load(std::memory_order_relaxed)) return;  // opted out: the pool is left as the application set it
@@ -43,7 +43,7 @@ static void keep_scratch_in_pool() {
   hipMemPool_t pool = nullptr;
   if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess || !pool) { (void)hipGetLastError(); return; }  // (retried on the next call)
   uint64_t cur = 0;
-  const uint64_t want = 256ull << 20;
+  const uint64_t want = 1024ull << 20;
   if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &cur) != hipSuccess) { (void)hipGetLastError(); cur = 0; }
   if (cur < want) {
     uint64_t v = want;
