@@ -357,6 +357,33 @@ def test_range_plans_cover_every_unit_exactly_once():
         _lib.set_option("cols_max_batch", 0)
 
 
+def test_wide_plan_whole_rounds_and_sliced_tail_for_any_cu_count():
+    """make_plan_wide (csrc/sqllm_capi.hip) on parts of 8 / 104 / 256 / 304 CUs: units of 64 rows x 8 column tiles; whole rounds
+    of one unit per CU run unsliced, the remaining units are cut into as many K slices as fit the idle CUs (each slice a whole
+    number of 4-unit groups, all of K covered, at most kMaxSlices = 120 slices, none shorter than 8 steps unless K is)."""
+    from squeezellm_amd import _lib
+
+    try:
+        for cus in (8, 104, 256, 304):
+            _lib.set_option("cu_count", cus)
+            for bits in (3, 4):
+                for K, N in ((5120, 13824), (13824, 5120), (4096, 4096), (8192, 22016), (1024, 776), (32, 4)):
+                    for batch in (64, 100, 512, 2048, 5000):
+                        _lib.set_option("mfma_wide_min_batch", 64)  # whatever the routing rule says about this shape
+                        p = _lib.plan_query(bits, K, N, batch=batch)
+                        U = K // (8 if bits == 4 else 32)
+                        units = -(-p["col_tiles"] // 8) * -(-batch // 64)
+                        full, ks, upw = units // cus * cus, p["k_slices"], p["groups_per_wave"]
+                        assert p["grid_y"] == 1 and p["dense_blocks"] == full + (units - full) * ks, (cus, bits, K, N, batch, p)
+                        assert upw % 4 == 0 and ks * upw >= U > (ks - 1) * upw and 1 <= ks <= 120, (cus, bits, K, N, batch, p)
+                        if ks > 1:
+                            assert (units - full) * ks <= cus, (cus, bits, K, N, batch, p)  # the sliced tail is one round
+                            assert upw >= (32 if bits == 4 else 8) or ks * upw < U + upw, (cus, bits, K, N, batch, p)
+    finally:
+        _lib.set_option("cu_count", 0)
+        _lib.set_option("mfma_wide_min_batch", 0)
+
+
 def test_product_sources_carry_no_measurement_routing():
     """The measured-and-not-adopted kernels, their options and their routing live in csrc/experimental/ (measurement
     library) and reach the host layer through the hooks of sqllm_host.h: the product's host source has no
