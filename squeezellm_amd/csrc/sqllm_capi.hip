@@ -388,6 +388,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "split_planes_min_batch")) { knobs().split_planes_min_batch.store(value); return SQLLM_OK; }
   if (!strcmp(name, "mfma_wide_min_batch")) { knobs().mfma_wide_min_batch.store(value); return SQLLM_OK; }
   if (!strcmp(name, "mfma_fuse_small")) { knobs().mfma_fuse_small.store(value ? 1 : 0); return SQLLM_OK; }
+  if (!strcmp(name, "mfma_fuse_sparse")) { knobs().mfma_fuse_sparse.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "scratch_pool_threshold")) { knobs().scratch_pool_threshold.store(value ? 1 : 0); return SQLLM_OK; }
   if (g_experimental.set_option) return g_experimental.set_option(name, value);  // (measurement library)
   return SQLLM_E_OPTION;
@@ -410,6 +411,7 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "split_planes_min_batch")) { *value = knobs().split_planes_min_batch.load(); return SQLLM_OK; }
   if (!strcmp(name, "mfma_wide_min_batch")) { *value = knobs().mfma_wide_min_batch.load(); return SQLLM_OK; }
   if (!strcmp(name, "mfma_fuse_small")) { *value = knobs().mfma_fuse_small.load(); return SQLLM_OK; }
+  if (!strcmp(name, "mfma_fuse_sparse")) { *value = knobs().mfma_fuse_sparse.load(); return SQLLM_OK; }
   if (!strcmp(name, "scratch_pool_threshold")) { *value = knobs().scratch_pool_threshold.load(); return SQLLM_OK; }
   if (g_experimental.get_option) return g_experimental.get_option(name, value);  // (measurement library)
   return SQLLM_E_OPTION;
@@ -655,6 +657,18 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
         // (running the two on different streams was tried: they do not overlap -- the dense kernel holds
         // every CU's registers -- and the two event waits cost 14 us per op)
         const bool sparse = sg.gm.csr_blocks + sg.gm.topx_blocks > 0;
+        // tile form: the sparse terms ride in the dense launch's grid (sqllm_fused_batched_split_all) -- always up to 32 rows
+        // (two workgroups per CU: 13B shapes 59-69 -> 55-57 us, 5120x5120 35-46 -> 28-38); from 33 rows, where the kernel
+        // takes a whole CU per workgroup, only while the sparse workgroups are fewer than the CUs (5120x5120 at 64 rows
+        // 81 -> 54 us; with 331 of them, 5120x13824, 112 -> 117: profiles/r04_mid_rows_fused_sparse.txt)
+        const bool fuse_sparse = sparse && !a.wide && knobs().mfma_split.load(std::memory_order_relaxed) &&
+                                 knobs().mfma_fuse_sparse.load(std::memory_order_relaxed) &&
+                                 (op->batch <= 32 || sg.gm.csr_blocks + sg.gm.topx_blocks < cu_count());
+        if (fuse_sparse) {
+          rc = static_cast<int>(sqllm::launch_batched_mfma_split_all(op->bits, a, static_cast<hipStream_t>(stream)));
+          if (rc != SQLLM_OK) return rc;
+          continue;
+        }
         if (sparse) {
           sqllm::LaunchArgs as = a;
           as.ev_stop = nullptr;

@@ -34,6 +34,7 @@ struct Knobs {
   std::atomic<int> scratch_pool_threshold{1};  // 0: never touch the release threshold of the device's default memory pool
   std::atomic<int> mfma_wide_min_batch{0};  // rows from which a workgroup takes EIGHT column tiles, one per wave, all on the same k's (0 = the measured rule: when those units fill 80 % of the CUs; a huge value: never)
   std::atomic<int> split_planes_min_batch{0};  // rows from which vec is split ONCE into bf16 planes in scratch (0 = the measured default; a huge value: never)
+  std::atomic<int> mfma_fuse_sparse{1};  // 17 rows up to the wide form: the op's CSR / top-X workgroups in the dense launch's grid (0: a launch of their own first)
   std::atomic<int> mfma_fuse_small{1};  // ... and up to 16 rows: the group's ops with their sparse terms as ONE launch of that kernel
 };
 constexpr int kMaxDevices = 32;

@@ -156,6 +156,7 @@ hipError_t launch_stream(int bits, const StreamArgs& sa, const GroupArgs& ga, hi
                          int ablate);
 hipError_t launch_batched_mfma(int bits, const LaunchArgs& a, hipStream_t stream);        // fp32 matrix instructions
 hipError_t launch_batched_mfma_split(int bits, const LaunchArgs& a, hipStream_t stream);  // bf16 matrix instructions on exactly split operands (sqllm_mfma_split.hip)
+hipError_t launch_batched_mfma_split_all(int bits, const LaunchArgs& a, hipStream_t stream);  // ... tile form, the op's sparse terms in the same grid
 hipError_t launch_batched_mfma_wide(int bits, const LaunchArgs& a, hipStream_t stream);   // ... in the wide form (sqllm_mfma_wide.hip)
 hipError_t launch_batched_cols(int bits, const LaunchArgs& a, hipStream_t stream);
 constexpr int kSplitFlagWgs = 256;  // workgroups (and flag words) of split_vec

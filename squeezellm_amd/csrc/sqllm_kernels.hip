@@ -358,7 +358,7 @@ sqllm_fused_batched(const float* x, const GroupArgs ga) {
 //   xT == null (no scratch, or the stream is capturing): it gathers from vec, 32 rows at a time.
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
-sqllm_sparse_batched(const float* x, const GroupArgs ga, const float* xT, int Bp) {
+sqllm_sparse_batched(const float* x, const GroupArgs ga, const float* xT, int Bp, int pass_rows) {
   constexpr int T = WAVES * 64;
   __shared__ __attribute__((aligned(16))) float lds[cmax(kCsrSpanMax + cmax(kCsrSpanMax, 64 * (kCsrXtSpan + 1) + 3 * kCsrChunk), kTopxLds)];
   const Segment sg = ga.seg[0];  // the whole descriptor in one round of scalar loads (see sqllm_fused_matvec)
@@ -366,11 +366,11 @@ sqllm_sparse_batched(const float* x, const GroupArgs ga, const float* xT, int Bp
   __builtin_amdgcn_sched_barrier(0);
   const KernelGeom& gm = sg.gm;
   const int sp = blockIdx.x;
-  // blockIdx.y = a block of kSparsePassRows rows: the CSR role with a transposed vec takes them two per lane where it can
-  // (csr_role), everything else in passes of 64 / 32
-  const int m0 = blockIdx.y * kSparsePassRows;
+  // blockIdx.y = a block of pass_rows rows (64, or kSparsePassRows = 128 where the grid stays large: launch_batched_sparse):
+  // the CSR role with a transposed vec takes 128 two per lane where it can (csr_role), everything else in passes of 64 / 32
+  const int m0 = blockIdx.y * pass_rows;
   int rows_here = gm.batch - m0;
-  if (rows_here > kSparsePassRows) rows_here = kSparsePassRows;
+  if (rows_here > pass_rows) rows_here = pass_rows;
   if (sp < gm.csr_blocks) {
     if (xT) {
       csr_role<T, 1, float, float, true>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, m0, rows_here, sp, lds, nullptr, 0, xT, Bp
@@ -754,11 +754,15 @@ hipError_t launch_batched_cols(int bits, const LaunchArgs& a, hipStream_t stream
 hipError_t launch_batched_sparse(const LaunchArgs& a, hipStream_t stream) {
   const KernelGeom& gm = a.ga.seg[0].gm;
   if (gm.csr_blocks + gm.topx_blocks <= 0) return hipSuccess;
-  dim3 grid(gm.csr_blocks + gm.topx_blocks, (gm.batch + kSparsePassRows - 1) / kSparsePassRows);
+  // blocks of 128 rows (two per lane in the CSR walk: fewer, longer workgroups) only where that leaves the chip several
+  // rounds of them -- at 128 rows it halved a grid of 662 and the launch went from 61 to 100 us
+  const int blocks = gm.csr_blocks + gm.topx_blocks;
+  const int pass_rows = (long long)blocks * ((gm.batch + kSparsePassRows - 1) / kSparsePassRows) >= 2048 ? kSparsePassRows : 64;
+  dim3 grid(blocks, (gm.batch + pass_rows - 1) / pass_rows);
   auto kern = sqllm_sparse_batched<kWaves>;
   const float* x = static_cast<const float*>(a.x);
-  if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga, a.xT, a.Bp);
-  else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga, a.xT, a.Bp);
+  if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga, a.xT, a.Bp, pass_rows);
+  else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga, a.xT, a.Bp, pass_rows);
   return hipGetLastError();
 }
 

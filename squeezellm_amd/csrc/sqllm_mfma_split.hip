@@ -236,6 +236,46 @@ sqllm_fused_batched_split(const float* x, const GroupArgs ga) {
                                          lds);
 }
 
+// The same with the op's sparse terms in the grid (17 rows up to the wide form's switch-over, one op per launch):
+// blockIdx.x = [CSR chunks | top-X slabs | pad to x8 | dense ranges], blockIdx.y = passes of 16 * MB rows.  As launches
+// of their own the sparse terms are pure latency on an underfilled chip -- 331 workgroups for a 13B gate/up op, 25 / 58 us
+// at 32 / 64 rows against 39 / 58 for the dense kernel (profiles/r04_kt_mid_rows.txt) -- here they run beside the
+// dense workgroups.  xT: the transposed copy of vec (sqllm_transpose_vec, launched before), or null: gathers.
+template <int BITS, int MB, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, (MB == 1 || (BITS == 4 && MB == 2)) ? 4 : 2)
+sqllm_fused_batched_split_all(const float* x, const GroupArgs ga, const float* xT, int Bp) {
+  constexpr int T = WAVES * 64;
+  __shared__ __attribute__((aligned(16))) float lds[cmax(split_lds_floats(BITS, WAVES),
+                                                         cmax(kCsrSpanMax + cmax(kCsrSpanMax, 64 * (kCsrXtSpan + 1) + 3 * kCsrChunk), kTopxLds))];
+  const Segment sg = ga.seg[0];
+  asm volatile("" ::SQLLM_SEG_OPERANDS(sg), "s"(x), "s"(xT));
+  __builtin_amdgcn_sched_barrier(0);
+  const KernelGeom& gm = sg.gm;
+  const int m0 = blockIdx.y * 16 * MB;
+  int rows_here = gm.batch - m0;
+  if (rows_here > 16 * MB) rows_here = 16 * MB;
+  const int bid = blockIdx.x;
+  const int d = bid - gm.dense_block0;
+  if (d >= 0 && d < gm.dense_blocks) {
+    dense_role_mfma_split<BITS, MB, WAVES>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, d, gm.col_tiles,
+                                           gm.units_total, gm.units_per_wg,
+                                           gm.dense_blocks == gm.col_tiles * gm.k_slices ? gm.k_slices * gm.units_per_wg : gm.units_total, lds);
+  } else if (bid < gm.csr_blocks) {
+    if (xT) {
+      csr_role<T, 1, float, float, true>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, m0, rows_here, bid, lds, nullptr, 0, xT, Bp);
+    } else {
+      constexpr int CBT = 32;  // (see sqllm_sparse_batched)
+      for (int bb = 0; bb < rows_here; bb += CBT) {
+        if (bb) __syncthreads();
+        csr_role<T, CBT, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, m0 + bb, rows_here - bb < CBT ? rows_here - bb : CBT, bid, lds,
+                                       nullptr, 0);
+      }
+    }
+  } else if (bid < gm.csr_blocks + gm.topx_blocks) {
+    topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, m0, rows_here, bid - gm.csr_blocks, lds);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Up to 16 rows: ONE launch for 1..kMaxSegments ops over one vec, all three terms -- the grid of the batch-1 fused
 // kernel (per op [CSR chunks | top-X slabs | pad to x8 | dense ranges]) with the split matrix-core role as its dense
@@ -297,6 +337,26 @@ hipError_t launch_split_inst(const LaunchArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+template <int BITS, int MB>
+hipError_t launch_split_all_inst(const LaunchArgs& a, hipStream_t stream) {
+  const KernelGeom& gm = a.ga.seg[0].gm;
+  dim3 grid(gm.dense_block0 + gm.dense_blocks, (gm.batch + 16 * MB - 1) / (16 * MB));
+  auto kern = sqllm_fused_batched_split_all<BITS, MB, kWaves>;
+  const float* x = static_cast<const float*>(a.x);
+  if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga, a.xT, a.Bp);
+  else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga, a.xT, a.Bp);
+  return hipGetLastError();
+}
+
+template <int BITS>
+hipError_t launch_split_all_bits(const LaunchArgs& a, hipStream_t stream) {
+  switch (mfma_row_blocks(a.ga.seg[0].gm.batch)) {
+    case 1: return launch_split_all_inst<BITS, 1>(a, stream);
+    case 2: return launch_split_all_inst<BITS, 2>(a, stream);
+    default: return launch_split_all_inst<BITS, 4>(a, stream);
+  }
+}
+
 template <int BITS>
 hipError_t launch_split_bits(const LaunchArgs& a, hipStream_t stream) {
   switch (mfma_row_blocks(a.ga.seg[0].gm.batch)) {
@@ -323,6 +383,11 @@ hipError_t launch_small_split(int bits, const LaunchArgs& a, hipStream_t stream)
     else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga, a.xT, a.Bp);
   }
   return hipGetLastError();
+}
+
+// one op (a.ga.seg[0]) in the tile form with its CSR / top-X workgroups in the same grid (a.xT: transposed vec or null)
+hipError_t launch_batched_mfma_split_all(int bits, const LaunchArgs& a, hipStream_t stream) {
+  return bits == 4 ? launch_split_all_bits<4>(a, stream) : launch_split_all_bits<3>(a, stream);
 }
 
 // one op (a.ga.seg[0]), operator ABI, batch rows through the bf16 matrix cores with split operands (dense term only);

@@ -47,8 +47,8 @@ def test_wide_batches_vs_oracle(qc, gpu, bits, K, N, kind, batch):
     assert H.rel_err(got, H.oracle_ref(case, x, mul, kind)) <= TOL_FP64
 
 
-@pytest.mark.parametrize("options", [dict(mfma_split=0), dict(mfma_fuse_small=0), dict(mfma_split=0, mfma_fuse_small=0)],
-                         ids=["fp32-instruction", "split-unfused", "fp32-unfused"])
+@pytest.mark.parametrize("options", [dict(mfma_split=0), dict(mfma_fuse_small=0), dict(mfma_split=0, mfma_fuse_small=0), dict(mfma_fuse_sparse=0)],
+                         ids=["fp32-instruction", "split-unfused", "fp32-unfused", "sparse-launch-of-its-own"])
 @pytest.mark.parametrize("bits,K,N", [(4, 1024, 132), (3, 1024, 776)])
 @pytest.mark.parametrize("batch", [9, 16, 40, 130])
 def test_wide_batch_routes_behind_options(qc, gpu, options, bits, K, N, batch):
