@@ -169,6 +169,10 @@ __device__ __forceinline__ void wide_phase(const u32x4 (&t)[Fmt<BITS>::kRows], c
           // (order: the words that need the earliest reads first -- pair 0's hi, mid, lo, then pair 1's ...)
           const int k = slot - 8, i = k / 3, kind = k % 3;
           Bn[4 * kind + i] = pack_b(e, 4 * kind + i);
+          // (pinned to its slot: the scheduling barriers bind the machine scheduler only -- the packing of a phase's LAST
+          // column, whose results leave the phase, was sunk behind all its matrix instructions by an earlier pass:
+          // tests/test_codegen_cpu.py found 19 of them back to back)
+          asm volatile("" : "+v"(Bn[4 * kind + i]));
         }
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -170,3 +170,73 @@ def test_wide_batch_sparse_kernel(asm):
         assert [l for l in body if "v_readlane_b32" in l], name  # scalar walk over the non-zeros
     for name, scratch, sspill, vgpr, vspill in _meta(asm, "_ZN5sqllm20sqllm_sparse_batched"):
         assert int(scratch) == 0 and int(vspill) == 0 and int(vgpr) <= 128, (name, scratch, vspill, vgpr)
+
+
+@pytest.fixture(scope="module")
+def asm_wide(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("asm_wide") / "w.s"
+    cmd = [hipcc, f"--offload-arch={B.ARCH}", *[f for f in B.FLAGS if f != "-fPIC"], "-S", "--cuda-device-only",
+           f"-I{B.INCLUDE}", f"-I{B.CSRC}", os.path.join(B.CSRC, "sqllm_mfma_wide.hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return out.read_text()
+
+
+def _loops(body):
+    """(start, end) line ranges of the backward branches of a kernel body."""
+    labels = {l.split(":")[0]: i for i, l in enumerate(body) if l.startswith(".LBB")}
+    out = []
+    for i, l in enumerate(body):
+        m = re.search(r"s_cbranch_\w+ (\.LBB\S+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            out.append((labels[m.group(1)], i))
+    return out
+
+
+def test_wide_form_kernels(asm_wide):
+    """The wide form of the split matrix-core kernel (csrc/sqllm_mfma_wide.hip): two waves per SIMD (<= 256 registers), no
+    FLAT, no scratch traffic inside a loop, no barrier at all; the planes kernels address their fragment loads with a
+    scalar base + one 32-bit offset; and the HAND SCHEDULE of the phase survives the compiler: in the main loops (two
+    steps = 160 matrix instructions with five partial products, 192 with six) a handful of matrix instructions (at most 6, with six products 8)
+    stand back to back -- the slots the next column's lookups leave free -- and the column's eight LDS reads sit between
+    them.  (Without the pins in wide_phase the packing of a phase's last column sank behind the phase: 19 in a row.)"""
+    ks = _family(asm_wide, "_ZN5sqllm16sqllm_fused_wide")
+    assert len(ks) == 4  # {3,4} bits x {planes, fp32 vec}
+    for name, scratch, sspill, vgpr, vspill in _meta(asm_wide, "_ZN5sqllm16sqllm_fused_wide"):
+        assert int(vgpr) <= 256, (name, vgpr)
+        if "ILi4E" in name:
+            assert int(scratch) == 0 and int(vspill) == 0, (name, scratch, vspill)
+    for name, body in ks.items():
+        assert not [l for l in body if re.match(r"\s+flat_", l)], name
+        assert not [l for l in body if re.match(r"\s+s_barrier", l)], name
+        planes = "ELb1E" in name
+        if planes:
+            assert [l for l in body if re.search(r"global_load_dwordx4 v\[\d+:\d+\], v\d+, s\[\d+:\d+\] offset:1024", l)], name
+        main = [(a, b) for a, b in _loops(body) if sum("v_mfma_f32_16x16x32_bf16" in l for l in body[a:b]) >= 160]
+        assert main, name
+        counts = set()
+        for a, b in main:
+            loop = body[a:b]
+            assert not [l for l in loop if "scratch_" in l], name
+            n_mfma = sum("v_mfma_f32_16x16x32_bf16" in l for l in loop)
+            if n_mfma not in (160, 192, 640, 768):  # (an enclosing loop: counted once through its inner ones)
+                continue
+            counts.add(n_mfma)
+            run = longest = 0
+            for l in loop:
+                t = l.strip()
+                if not t or t.startswith(";") or t.startswith("."):
+                    continue
+                if t.startswith("v_mfma"):
+                    run += 1
+                    longest = max(longest, run)
+                elif not t.startswith("s_"):  # (scalar bookkeeping and waits do not take a vector issue slot)
+                    run = 0
+            assert longest <= (6 if n_mfma % 160 == 0 else 8), (name, n_mfma, longest)  # (free slots 1, 6, 7, 20-23 and, at 3 bits, a slot 0 without instructions)
+            per_col = 20 if n_mfma % 160 == 0 else 24
+            assert sum(l.strip().startswith("ds_read_b64") for l in loop) * per_col >= n_mfma * 8, name  # (at least) 8 lookups per column of 20 / 24 matrix instructions
+        assert counts, name
+        if planes:
+            assert len(counts) == 2, (name, counts)  # the five- and the six-product role
