@@ -171,6 +171,35 @@ def test_wide_form_in_a_captured_graph(gpu, scratch_in_capture):
         _lib.set_option("scratch_in_capture", 1)
 
 
+@pytest.mark.parametrize("vec", ["fp16-born", "fp32"])
+@pytest.mark.parametrize("bits", [3, 4])
+def test_wide_form_at_13b_size_agrees_with_the_batch1_operator(qc, gpu, bits, vec):
+    """BASELINE configs[3] shape at a size the CPU oracle cannot check in seconds: LLaMA-13B gate_proj (5120 x 13824), w + 0.45 %
+    CSR outliers + top-10 rows, 600 rows -- the wide form by the default routing (ten 64-row blocks, the last with 24 live
+    rows; whole rounds + a sliced tail with slabs; sparse terms as launches of their own).  Sampled rows against the
+    batch-1 hybrid operator on the same operands, which the oracle pins at this shape (test_gpu_parity.py)."""
+    import torch
+
+    from squeezellm_amd import _lib, synth
+
+    K, N, B = 5120, 13824, 600
+    assert _lib.plan_query(bits, K, N, batch=B)["grid_y"] == 1  # (the wide form's 1-D grid)
+    lay = synth.make_layer(K, N, bits, sparse_frac=0.0045, topX=10, heavy_rows=10, device=gpu, seed=31 + bits)
+    g = torch.Generator(device=gpu).manual_seed(5)
+    x = torch.randn((B, K), device=gpu, generator=g, dtype=torch.float16).float() if vec == "fp16-born" else torch.randn((B, K), device=gpu, generator=g)
+    y0 = torch.randn((B, N), device=gpu, generator=g) * 0.01
+    y = y0.clone()
+    name = f"vecquant{bits}matmul_spmv_hybrid_nuq_perchannel"
+    args = (lay["rows"], lay["cols"], lay["vals"])
+    getattr(qc, name + "_batched")(*args, x, lay["full_rows"], lay["full_row_indices"], y, N, lay["qweight"], lay["lookup_table"])
+    for r in (0, 63, 64, 300, 575, 599):
+        yr = y0[r].clone()
+        getattr(qc, name)(*args, x[r].contiguous(), lay["full_rows"], lay["full_row_indices"], yr, N, lay["qweight"], lay["lookup_table"])
+        torch.cuda.synchronize()
+        err = float((y[r] - yr).abs().max() / yr.abs().max())
+        assert err <= 2e-5, (r, err)
+
+
 def _routing(mfma_min, cols_min, cols_max):
     from squeezellm_amd import _lib
 
