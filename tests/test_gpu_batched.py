@@ -116,6 +116,21 @@ def test_wide_form_vs_oracle(qc, gpu, vec, planes, bits, K, N, batch):
 
 
 @pytest.mark.parametrize("bits", [3, 4])
+def test_wide_form_many_row_blocks(qc, gpu, bits):
+    """4100 rows (65 blocks of 64, the last with 4 live rows) x 5 column groups = 325 units on the real CU count: a whole round
+    of unsliced units and a sliced tail; hybrid op, so the sparse launch takes its 128-row blocks too."""
+    from squeezellm_amd import _lib
+
+    case = H.make_case(bits, 512, 2500, sparse=0.01, topX=4, heavy_rows=2, seed=91 + bits)
+    try:
+        _lib.set_option("mfma_wide_min_batch", 64)
+        x, mul, got = run_batched(qc, gpu, case, "hybrid", 4100)
+    finally:
+        _lib.set_option("mfma_wide_min_batch", 0)
+    assert H.rel_err(got, H.oracle_ref(case, x, mul, "hybrid")) <= TOL_FP64
+
+
+@pytest.mark.parametrize("bits", [3, 4])
 @pytest.mark.parametrize("cus", [8, 24])
 def test_wide_form_whole_rounds(qc, gpu, bits, cus):
     """Planned for a part of 8 / 24 CUs (option cu_count), 3 row blocks x 9 column groups = 27 units make whole rounds of
