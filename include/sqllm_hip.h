@@ -287,8 +287,8 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     (sqllm_launch_group) -- is ONE launch of the split matrix-core kernel with its CSR / top-X workgroups in
  *                     the same grid; 0: one launch per op plus a launch for its sparse terms (as from 17 rows on)
  *   "mfma_fuse_sparse" 1 (default, with mfma_split): from 17 rows up to the wide form an op's CSR / top-X workgroups run in the grid of
- *                     its dense launch -- always up to 32 rows, beyond that while they are fewer than the CUs; 0: a launch of
- *                     their own first
+ *                     its dense launch -- always up to 64 rows (33-64 rows: as two 32-row passes if they outnumber the CUs),
+ *                     beyond that while they are fewer than the CUs; 0: a launch of their own first
  *   "mfma_wide_min_batch"  0 (default): with mfma_split, the WIDE form of that kernel -- workgroups of eight 64-column tiles, one per
  *                     wave, all on the same k's: the vec values of a step are fetched once per workgroup instead of once per tile --
  *                     takes over from 64 rows up once batch * K * N >= 5.7e9 (3-bit: 4e9; three times that while the stream is

@@ -168,9 +168,9 @@ void fill_segment(const sqllm_op* op, sqllm::Segment* sg) {
 // workgroups, none of them short (N / 64 is rarely a multiple of the CU count: cutting K slices per
 // column tile left the last round 27 % full on the 13B gate/up shape).  A range is a whole number
 // of workgroup steps (waves x 4 units); one that crosses a tile boundary costs a second piece.
-void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1) {
+void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1, int row_blocks = 0) {
   make_plan(op, gm, 1);
-  const int mb = sqllm::mfma_row_blocks(gm->batch);
+  const int mb = row_blocks > 0 ? row_blocks : sqllm::mfma_row_blocks(gm->batch);
   const int grid_y = (gm->batch + 16 * mb - 1) / (16 * mb);
   const int step = sqllm::kWaves * 4;
   const long long total_units = (long long)gm->col_tiles * gm->units_total;
@@ -661,9 +661,18 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
         // (two workgroups per CU: 13B shapes 59-69 -> 55-57 us, 5120x5120 35-46 -> 28-38); from 33 rows, where the kernel
         // takes a whole CU per workgroup, only while the sparse workgroups are fewer than the CUs (5120x5120 at 64 rows
         // 81 -> 54 us; with 331 of them, 5120x13824, 112 -> 117: profiles/r04_mid_rows_fused_sparse.txt)
-        const bool fuse_sparse = sparse && !a.wide && knobs().mfma_split.load(std::memory_order_relaxed) &&
-                                 knobs().mfma_fuse_sparse.load(std::memory_order_relaxed) &&
-                                 (op->batch <= 32 || sg.gm.csr_blocks + sg.gm.topx_blocks < cu_count());
+        const bool may_fuse = sparse && !a.wide && knobs().mfma_split.load(std::memory_order_relaxed) &&
+                              knobs().mfma_fuse_sparse.load(std::memory_order_relaxed);
+        bool fuse_sparse = may_fuse && (op->batch <= 32 || sg.gm.csr_blocks + sg.gm.topx_blocks < cu_count());
+        if (may_fuse && !fuse_sparse && op->batch <= 64) {
+          // 33-64 rows with more sparse workgroups than CUs: two passes of 32 rows on the kernel that leaves room for two
+          // workgroups per CU, sparse terms in its grid, instead of one 64-row pass + their own launch
+          // (profiles/r04_mid_rows_fused_sparse.txt, "mb2")
+          a.row_blocks = 2;
+          make_plan_mfma(op, &sg.gm, 1, 2);
+          for (int j = 1; j <= sqllm::kMaxSegments; ++j) a.ga.block0[j] = sg.gm.dense_block0 + sg.gm.dense_blocks;
+          fuse_sparse = true;
+        }
         if (fuse_sparse) {
           rc = static_cast<int>(sqllm::launch_batched_mfma_split_all(op->bits, a, static_cast<hipStream_t>(stream)));
           if (rc != SQLLM_OK) return rc;

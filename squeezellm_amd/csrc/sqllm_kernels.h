@@ -111,6 +111,7 @@ struct LaunchArgs {
   bool wide = false;  // the geometry is make_plan_wide's: workgroups of eight column tiles (sqllm_mfma_wide.hip: sqllm_fused_wide)
   int wide_full_units = 0;  // ... and this many of them over all of K; the rest in gm.k_slices slices
   float* wide_slabs = nullptr;  // scratch for the slices' sums (wide_slab_bytes), or null: they add atomically
+  int row_blocks = 0;  // tile form: blocks of 16 rows per pass (1, 2 or 4); 0 = mfma_row_blocks(batch)
 };
 
 // ---- streaming batch-1 kernel (sqllm_stream.hip) ----

@@ -350,7 +350,7 @@ hipError_t launch_split_all_inst(const LaunchArgs& a, hipStream_t stream) {
 
 template <int BITS>
 hipError_t launch_split_all_bits(const LaunchArgs& a, hipStream_t stream) {
-  switch (mfma_row_blocks(a.ga.seg[0].gm.batch)) {
+  switch (a.row_blocks > 0 ? a.row_blocks : mfma_row_blocks(a.ga.seg[0].gm.batch)) {
     case 1: return launch_split_all_inst<BITS, 1>(a, stream);
     case 2: return launch_split_all_inst<BITS, 2>(a, stream);
     default: return launch_split_all_inst<BITS, 4>(a, stream);
