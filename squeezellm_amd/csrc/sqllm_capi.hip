@@ -426,8 +426,17 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   sqllm::KernelGeom gm;
   const bool mfma = takes_mfma_path(op);
   const bool wide = mfma && takes_wide_path(op, true, false);  // (as launched outside a capture, scratch at hand)
+  int row_blocks = 0;
   if (wide) (void)make_plan_wide(op, &gm);
-  else if (mfma) make_plan_mfma(op, &gm);
+  else if (mfma) {
+    make_plan_mfma(op, &gm);
+    // (33-64 rows with more sparse workgroups than CUs: two 32-row passes, sparse terms in the grid -- launch_group_with_events)
+    if (op->batch > 32 && op->batch <= 64 && gm.csr_blocks + gm.topx_blocks >= cu_count() && knobs().mfma_split.load(std::memory_order_relaxed) &&
+        knobs().mfma_fuse_sparse.load(std::memory_order_relaxed)) {
+      row_blocks = 2;
+      make_plan_mfma(op, &gm, 1, 2);
+    }
+  }
   else if (takes_cols_path(op)) make_plan_cols(op, &gm);
   else make_plan(op, &gm);
   plan->col_tiles = gm.col_tiles;
@@ -437,7 +446,7 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   plan->csr_blocks = gm.csr_blocks;
   plan->topx_blocks = gm.topx_blocks;
   plan->grid_x = mfma ? gm.dense_blocks : gm.dense_block0 + gm.dense_blocks;  // (wide batches: the sparse terms are a launch of their own)
-  const int rows_per_pass = wide ? (gm.batch > 0 ? gm.batch : 1) : mfma ? 16 * sqllm::mfma_row_blocks(gm.batch) : sqllm::batch_tile(gm.batch);
+  const int rows_per_pass = wide ? (gm.batch > 0 ? gm.batch : 1) : mfma ? 16 * (row_blocks ? row_blocks : sqllm::mfma_row_blocks(gm.batch)) : sqllm::batch_tile(gm.batch);
   plan->grid_y = (gm.batch + rows_per_pass - 1) / rows_per_pass;
   return SQLLM_OK;
 }
