@@ -15,9 +15,13 @@
  *   - `mul` is ACCUMULATED INTO, never overwritten (the caller pre-loads bias or zeros:
  *     squeezellm/quant.py:214-219, :316-318);
  *   - qweight is int32 [height, width] = [K/32*bits, N]; lookup_table is [N, 2^bits];
- *   - the callee allocates nothing, retains nothing, never synchronises, and enqueues exactly one
- *     kernel on `stream` (NULL = the legacy default stream, which is what the reference used;
- *     the Python binding passes torch's current stream so calls are graph-capturable);
+ *   - the callee retains nothing and never synchronises; it enqueues its kernels on `stream` (NULL = the
+ *     legacy default stream, which is what the reference used; the Python binding passes torch's current
+ *     stream so calls are graph-capturable): exactly ONE kernel and no allocation for batch 1 and for
+ *     batches up to 16 rows; the `_ws` entry points (sqllm_launch_ws ...) allocate nothing at ANY batch --
+ *     what a wider batch needs beside its operands comes out of the caller's workspace, as the reference's
+ *     launchers allocate nothing (quant_cuda_kernel.cu:580-657); the workspace-less names fall back to
+ *     stream-ordered scratch there (see sqllm_launch);
  *   - return value: 0 on success, a negative SQLLM_E_* code for rejected arguments (the reference
  *     validated nothing and read out of bounds instead), or a positive hipError_t from the launch.
  *
@@ -76,8 +80,25 @@ typedef struct sqllm_op {
  * scratch (hipMallocAsync / hipFreeAsync on `stream`; only with a CSR term), the sparse terms, (wide
  * form only: "mfma_wide_min_batch") the split of vec into bf16 planes, again in such scratch, and
  * the dense term on the matrix cores.  Inside a stream capture the scratch becomes memory nodes of
- * the graph unless option "scratch_in_capture" is 0.  No host synchronisation in either case. */
+ * the graph unless option "scratch_in_capture" is 0.  No host synchronisation in either case.
+ * Callers that own a workspace use sqllm_launch_ws instead: nothing is allocated then. */
 int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream);
+
+/* The same with a CALLER-OWNED workspace -- the form that keeps the reference's contract at every batch
+ * (its launchers allocate nothing: quant_cuda_kernel.cu:580-657): `workspace` is `workspace_bytes` of
+ * device memory, 16-byte aligned, contents irrelevant before and after; sqllm_workspace_bytes(ops, n)
+ * says how much the op (n = 1) or the group can use (0: none -- batch 1, batch tiles).  It serves one
+ * launch at a time: launches on one stream may share it, concurrent streams may not.  What lives in it:
+ *   2..16 rows (fused small launch)  vec transposed, xT[k][rows rounded up to 2 / 4 / 8 / 16]: the CSR walk of
+ *            the dense workgroups then reads one cache line per non-zero instead of one per non-zero and
+ *            row (one small kernel in front of the launch; only with a CSR term);
+ *   17+ rows  what sqllm_launch takes from stream-ordered scratch: vec transposed, its bf16 planes, the
+ *            wide form's slabs.
+ * A NULL or too small workspace is not an error: 2..16 rows then gather from vec itself (no allocation
+ * either), 17+ rows fall back to the stream-ordered scratch of sqllm_launch.  A stream capture of a `_ws`
+ * launch with a sufficient workspace contains kernel nodes only. */
+int64_t sqllm_workspace_bytes(const sqllm_op* ops, int32_t n_ops);
+int sqllm_launch_ws(const sqllm_op* op, void* workspace, int64_t workspace_bytes, sqllm_stream_t stream);
 
 /* Enqueue `n_ops` ops back to back on `stream` from one host call (a decode pass over a stack of
  * QuantLinearLUT layers costs one FFI crossing instead of n_ops).  Stops at the first error and
@@ -90,11 +111,16 @@ int sqllm_launch_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t str
  * are simply divided between them.  Halves the launch count of a LLaMA decode pass, which matters
  * because each launch carries ~2-3 us of fixed cost against 1-4 us of streaming. */
 int sqllm_launch_group(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t stream);
+int sqllm_launch_group_ws(const sqllm_op* ops, int32_t n_ops, void* workspace, int64_t workspace_bytes, sqllm_stream_t stream);
 
 /* A whole pass as consecutive groups: group g covers the next group_sizes[g] entries of `ops`.
  * *n_done (may be NULL) receives the number of groups enqueued. */
 int sqllm_launch_groups(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups,
                         sqllm_stream_t stream, int32_t* n_done);
+/* ... with one workspace for all of them (they run one after the other on `stream`): the largest
+ * sqllm_workspace_bytes of any group serves the pass */
+int sqllm_launch_groups_ws(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups, void* workspace,
+                           int64_t workspace_bytes, sqllm_stream_t stream, int32_t* n_done);
 
 /* Measurement aid (used by bench.py's roofline leg, never on the serving path): enqueue the ops like
  * sqllm_launch_sequence, but attach a start/stop event pair to EVERY kernel dispatch
@@ -107,6 +133,8 @@ int sqllm_profile_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t st
 /* the same for grouped launches: avg_us[0..n_groups) */
 int sqllm_profile_groups(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups,
                          sqllm_stream_t stream, int32_t reps, float* avg_us);
+int sqllm_profile_groups_ws(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups, void* workspace,
+                            int64_t workspace_bytes, sqllm_stream_t stream, int32_t reps, float* avg_us);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused linear: the whole matvec branch of QuantLinearLUT.forward in one kernel.

@@ -67,6 +67,11 @@ SIGNATURES = {
     "sqllm_launch_group": [POINTER(SqllmOp), c_int32, P],
     "sqllm_launch_groups": [POINTER(SqllmOp), POINTER(c_int32), c_int32, P, POINTER(c_int32)],
     "sqllm_profile_groups": [POINTER(SqllmOp), POINTER(c_int32), c_int32, P, c_int32, POINTER(ctypes.c_float)],
+    "sqllm_workspace_bytes": [POINTER(SqllmOp), c_int32],
+    "sqllm_launch_ws": [POINTER(SqllmOp), P, ctypes.c_int64, P],
+    "sqllm_launch_group_ws": [POINTER(SqllmOp), c_int32, P, ctypes.c_int64, P],
+    "sqllm_launch_groups_ws": [POINTER(SqllmOp), POINTER(c_int32), c_int32, P, ctypes.c_int64, P, POINTER(c_int32)],
+    "sqllm_profile_groups_ws": [POINTER(SqllmOp), POINTER(c_int32), c_int32, P, ctypes.c_int64, P, c_int32, POINTER(ctypes.c_float)],
     "sqllm_linear_workspace_bytes": [POINTER(SqllmOp)],
     "sqllm_linear_f16": [POINTER(SqllmLinear), P],
     "sqllm_linear_f16_groups": [POINTER(SqllmLinear), POINTER(c_int32), c_int32, P, POINTER(c_int32)],
@@ -104,10 +109,12 @@ def load() -> ctypes.CDLL:
         )
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
+        if os.environ.get("SQLLM_LIB") and not hasattr(lib, name):
+            continue  # (measurement aid: an older build of the library under SQLLM_LIB lacks the newer entry points)
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = argtypes
         fn.restype = (c_char_p if name == "sqllm_error_string" else
-                      ctypes.c_int64 if name == "sqllm_linear_workspace_bytes" else c_int)
+                      ctypes.c_int64 if name in ("sqllm_linear_workspace_bytes", "sqllm_workspace_bytes") else c_int)
     if lib.sqllm_abi_version() != 1:
         raise RuntimeError(f"libsqllm_hip.so ABI {lib.sqllm_abi_version()} != 1 expected by this package")
     _lib = lib
@@ -144,6 +151,19 @@ def linear_workspace_bytes(N: int, batch: int = 0) -> int:
     """Bytes of zero-filled device memory one fused linear of this shape needs (no GPU needed)."""
     op = SqllmOp(N=N, batch=batch)
     return int(load().sqllm_linear_workspace_bytes(ctypes.byref(op)))
+
+
+def workspace_bytes(bits: int, K: int, N: int, batch: int, nnz: int = 0, topX: int = 0, n_ops: int = 1) -> int:
+    """Bytes of caller workspace a batched op (or a group of `n_ops` such ops over one vec) can use (no GPU needed)."""
+    ops = (SqllmOp * n_ops)()
+    for op in ops:
+        op.bits, op.batch, op.K, op.N, op.nnz, op.topX = bits, batch, K, N, nnz, topX
+        op.vec = op.qweight = op.mul = op.lookup_table = 16  # (sizing looks at shapes and at which pointers are non-NULL)
+        if nnz:
+            op.rows = op.cols = op.vals = 16
+        if topX:
+            op.full_rows = op.full_row_indices = 16
+    return int(load().sqllm_workspace_bytes(ops, n_ops))
 
 
 def plan_query(bits: int, K: int, N: int, batch: int = 0, nnz: int = 0, topX: int = 0) -> dict:

@@ -168,7 +168,9 @@ void fill_segment(const sqllm_op* op, sqllm::Segment* sg) {
 // workgroups, none of them short (N / 64 is rarely a multiple of the CU count: cutting K slices per
 // column tile left the last round 27 % full on the 13B gate/up shape).  A range is a whole number
 // of workgroup steps (waves x 4 units); one that crosses a tile boundary costs a second piece.
-void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1, int row_blocks = 0) {
+// `reserve`: workgroups of the launch that are not dense ranges (the fused small launch's top-X slabs) -- they hold
+// slots of the one round too.
+void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1, int row_blocks = 0, int wgs_per_cu = 0, int reserve = 0) {
   make_plan(op, gm, 1);
   const int mb = row_blocks > 0 ? row_blocks : sqllm::mfma_row_blocks(gm->batch);
   const int grid_y = (gm->batch + 16 * mb - 1) / (16 * mb);
@@ -178,7 +180,10 @@ void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch
   bool aligned = false;
   if (upw <= 0) {
     int target = knobs().target_wgs.load(std::memory_order_relaxed);
-    if (target <= 0) target = (mb == 4 ? 1 : 2) * cu_count();
+    if (target <= 0) {
+      target = (wgs_per_cu > 0 ? wgs_per_cu : mb == 4 ? 1 : 2) * cu_count();
+      if (reserve > 0 && target - reserve >= target / 2) target -= reserve;
+    }
     target = (target + ops_in_launch - 1) / ops_in_launch;  // the ops of a group share the launch's workgroups
     long long ranges = (target + grid_y - 1) / grid_y;
     if (ranges < 1) ranges = 1;
@@ -255,6 +260,32 @@ bool takes_wide_path(const sqllm_op* op, bool with_scratch, bool capturing) {
   return 5 * units >= 4 * (long long)cu_count();
 }
 
+// The CSR term walked by the dense workgroups themselves (csr_tile_fold, sqllm_roles.h): no chunk workgroups in the grid.
+void fold_csr_into_dense(sqllm::KernelGeom* gm) {
+  gm->fold_csr = gm->nnz > 0 ? 1 : 0;
+  gm->csr_blocks = 0;
+  gm->dense_block0 = (gm->sparse_last & 1) ? gm->topx_blocks : (gm->topx_blocks + 7) / 8 * 8;
+}
+
+// top-X workgroups of an op in the fused small launch: with the transposed vec at hand 8 (K <= 40 slabs) or 16 of them
+// share the op's slabs (topx_role_xt: all batch rows at once) -- few enough to hold their slots beside ONE round of
+// dense workgroups; without it one workgroup per slab, as everywhere else
+int small_topx_blocks(const sqllm_op* op, bool with_xT, int ops_in_launch) {
+  if (!(op->full_rows && op->topX > 0)) return 0;
+  const int slabs = (op->K + sqllm::kTopxRows - 1) / sqllm::kTopxRows;
+  if (!with_xT || op->topX > 16) return slabs;
+  // (an op alone in its launch is short-lived -- 13B o_proj: 11 us -- and leaves slots free: more, shorter-lived workgroups)
+  const int want = ops_in_launch == 1 ? (slabs <= 24 ? 24 : 16) : slabs <= 40 ? 8 : 16;
+  return slabs < want ? slabs : want;
+}
+
+// dense workgroups per CU the fused small launch's planner aims at: as many as the kernel holds (two, by its registers:
+// capped at 80 for a third one, the dense role measured 10 % slower -- profiles/r05_small_split_register_cap.txt)
+int small_wgs_per_cu_of(const sqllm_op* op) {
+  const int v = knobs().small_wgs_per_cu.load(std::memory_order_relaxed);
+  return v > 0 ? v : 2;
+}
+
 int mfma_min_batch_of(const sqllm_op* op) {
   const int v = knobs().mfma_min_batch.load(std::memory_order_relaxed);
   // 3-bit: 17 until round 4 -- from 9 rows the fused small-batch launch of the split matrix-core kernel beats the
@@ -269,6 +300,13 @@ int cols_max_batch_of(const sqllm_op* op) {
 }
 
 bool takes_mfma_path(const sqllm_op* op) { return op->batch >= 1 && op->batch >= mfma_min_batch_of(op); }
+
+// does this op (or the group it leads) run as the fused small launch of the split matrix-core kernel (sqllm_fused_small_split)?
+bool takes_small_split(const sqllm_op* op) {
+  if (op->K >= (1 << 26)) return false;  // (its folded CSR walk packs a local row beside the column)
+  return takes_mfma_path(op) && op->batch <= sqllm::kSmallSplitRows && knobs().mfma_split.load(std::memory_order_relaxed) &&
+         knobs().mfma_fuse_small.load(std::memory_order_relaxed);
+}
 
 // Geometry of the small-batch column-lane kernel: passes of batch_tile(batch) <= 8 rows
 // (blockIdx.y); the dense work of a pass is cut into equal ranges of the flattened
@@ -381,7 +419,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "mfma_min_batch")) { knobs().mfma_min_batch.store(value); return SQLLM_OK; }
   if (!strcmp(name, "cols_min_batch")) { knobs().cols_min_batch.store(value); return SQLLM_OK; }
   if (!strcmp(name, "cols_max_batch")) { knobs().cols_max_batch.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "sparse_transpose")) { knobs().sparse_transpose.store(value ? 1 : 0); return SQLLM_OK; }
+  if (!strcmp(name, "sparse_transpose")) { knobs().sparse_transpose.store(value); return SQLLM_OK; }
   if (!strcmp(name, "scratch_in_capture")) { knobs().scratch_in_capture.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "validate_csr")) { knobs().validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "mfma_split")) { knobs().mfma_split.store(value ? 1 : 0); return SQLLM_OK; }
@@ -390,6 +428,9 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "mfma_fuse_small")) { knobs().mfma_fuse_small.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "mfma_fuse_sparse")) { knobs().mfma_fuse_sparse.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "scratch_pool_threshold")) { knobs().scratch_pool_threshold.store(value ? 1 : 0); return SQLLM_OK; }
+  if (!strcmp(name, "csr_fold")) { knobs().csr_fold.store(value ? 1 : 0); return SQLLM_OK; }
+  if (!strcmp(name, "small_wgs_per_cu")) { knobs().small_wgs_per_cu.store(value); return SQLLM_OK; }
+  if (!strcmp(name, "small_reserve_topx")) { knobs().small_reserve_topx.store(value ? 1 : 0); return SQLLM_OK; }
   if (g_experimental.set_option) return g_experimental.set_option(name, value);  // (measurement library)
   return SQLLM_E_OPTION;
 }
@@ -413,6 +454,9 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "mfma_fuse_small")) { *value = knobs().mfma_fuse_small.load(); return SQLLM_OK; }
   if (!strcmp(name, "mfma_fuse_sparse")) { *value = knobs().mfma_fuse_sparse.load(); return SQLLM_OK; }
   if (!strcmp(name, "scratch_pool_threshold")) { *value = knobs().scratch_pool_threshold.load(); return SQLLM_OK; }
+  if (!strcmp(name, "csr_fold")) { *value = knobs().csr_fold.load(); return SQLLM_OK; }
+  if (!strcmp(name, "small_wgs_per_cu")) { *value = knobs().small_wgs_per_cu.load(); return SQLLM_OK; }
+  if (!strcmp(name, "small_reserve_topx")) { *value = knobs().small_reserve_topx.load(); return SQLLM_OK; }
   if (g_experimental.get_option) return g_experimental.get_option(name, value);  // (measurement library)
   return SQLLM_E_OPTION;
 }
@@ -438,14 +482,26 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
     }
   }
   else if (takes_cols_path(op)) make_plan_cols(op, &gm);
-  else make_plan(op, &gm);
+  else {
+    make_plan(op, &gm);
+    if (gm.batch >= 2 && gm.nnz > 0 && knobs().csr_fold.load(std::memory_order_relaxed)) fold_csr_into_dense(&gm);  // (as launch_group_with_events)
+  }
+  const bool small_split = mfma && !wide && takes_small_split(op);
+  if (small_split) {  // the fused small launch: CSR term folded into the dense workgroups, top-X slabs in the grid
+    // (as launched with a workspace: vec transposed, 8-16 top-X workgroups, the dense ranges planned beside them)
+    const bool with_xT = knobs().sparse_transpose.load(std::memory_order_relaxed) != 0;
+    make_plan_mfma(op, &gm, 1, 0, small_wgs_per_cu_of(op),
+                   (with_xT || knobs().small_reserve_topx.load(std::memory_order_relaxed)) ? (small_topx_blocks(op, with_xT, 1) + 7) / 8 * 8 : 0);
+    gm.topx_blocks = small_topx_blocks(op, with_xT, 1);
+    fold_csr_into_dense(&gm);
+  }
   plan->col_tiles = gm.col_tiles;
   plan->k_slices = gm.k_slices;
   plan->groups_per_wave = gm.units_per_wg;
   plan->dense_blocks = gm.dense_blocks;
   plan->csr_blocks = gm.csr_blocks;
   plan->topx_blocks = gm.topx_blocks;
-  plan->grid_x = mfma ? gm.dense_blocks : gm.dense_block0 + gm.dense_blocks;  // (wide batches: the sparse terms are a launch of their own)
+  plan->grid_x = (mfma && !small_split) ? gm.dense_blocks : gm.dense_block0 + gm.dense_blocks;  // (wide batches: the sparse terms are a launch of their own)
   const int rows_per_pass = wide ? (gm.batch > 0 ? gm.batch : 1) : mfma ? 16 * (row_blocks ? row_blocks : sqllm::mfma_row_blocks(gm.batch)) : sqllm::batch_tile(gm.batch);
   plan->grid_y = (gm.batch + rows_per_pass - 1) / rows_per_pass;
   return SQLLM_OK;
@@ -471,24 +527,19 @@ int64_t sqllm_linear_workspace_bytes(const sqllm_op* op) {
 // Without scratch: the CSR role gathers from vec, the wide form splits in registers and its slices add atomically.
 constexpr int kSplitPlanesMinBatch = 64;
 struct WideScratch {
-  void* block = nullptr;
+  void* block = nullptr;  // stream-ordered allocation of our own (freed by the destructor), null when the caller's workspace serves
   float* xT = nullptr;
   int Bp = 0;
   void* planes = nullptr;
   uint32_t* flags = nullptr;
   float* slabs = nullptr;
-  bool capturing = false;
+  bool capturing = false;  // ... and the scratch would have to be allocated inside the capture (memory nodes)
   hipStream_t s = nullptr;
-  // ops[0] is validated; *e0 (the start event of a profiled group) goes to the first kernel enqueued here, if any
-  int acquire(const sqllm_op* ops, int n, sqllm_stream_t stream, hipEvent_t* e0) {
-    s = static_cast<hipStream_t>(stream);
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (!(hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone)) {
-      (void)hipGetLastError();
-      capturing = true;
-    }
-    if (capturing && !knobs().scratch_in_capture.load(std::memory_order_relaxed)) return SQLLM_OK;
-    if (!ops[0].vec || ops[0].batch <= 0 || ops[0].K <= 0) return SQLLM_OK;
+  // what a group wants, in bytes: [xT | planes | flags | slabs]
+  struct Layout { uint64_t xt = 0, planes = 0, flags = 0, slabs = 0; int Bp = 0; uint64_t total() const { return xt + planes + flags + slabs; } };
+  static Layout layout(const sqllm_op* ops, int n, bool capturing) {
+    Layout L;
+    if (!ops || n < 1 || ops[0].batch <= 0 || ops[0].K <= 0) return L;
     bool any_csr = false, any_wide = false;
     uint64_t slab_bytes = 0;
     for (int i = 0; i < n; ++i) {
@@ -505,32 +556,54 @@ struct WideScratch {
     if (from == 0) from = kSplitPlanesMinBatch;
     const uint64_t chunks = sqllm::split_planes_chunks(ops[0].batch, ops[0].K);
     const bool want_planes = any_wide && ops[0].batch >= from && chunks < (1ull << 31);  // (32-bit chunk numbers in the kernel)
-    if (!want_xT && !want_planes) return SQLLM_OK;
-    Bp = (ops[0].batch + 63) / 64 * 64;
-    const uint64_t xt_bytes = want_xT ? (uint64_t)ops[0].K * Bp * sizeof(float) : 0;
-    const uint64_t plane_bytes = want_planes ? chunks * 16 : 0;
-    const uint64_t flag_bytes = want_planes ? (sqllm::kSplitFlagWgs * sizeof(uint32_t) + 15) / 16 * 16 : 0;
-    if (!want_planes) slab_bytes = 0;
-    keep_scratch_in_pool();
-    if (hipMallocAsync(&block, xt_bytes + plane_bytes + flag_bytes + slab_bytes, s) != hipSuccess || !block) {
-      (void)hipGetLastError();  // no scratch
-      block = nullptr;
-      Bp = 0;
-      return SQLLM_OK;
+    if (!want_xT && !want_planes) return L;
+    L.Bp = (ops[0].batch + 63) / 64 * 64;
+    L.xt = want_xT ? (uint64_t)ops[0].K * L.Bp * sizeof(float) : 0;
+    L.planes = want_planes ? chunks * 16 : 0;
+    L.flags = want_planes ? (sqllm::kSplitFlagWgs * sizeof(uint32_t) + 15) / 16 * 16 : 0;
+    L.slabs = want_planes ? slab_bytes : 0;
+    return L;
+  }
+  // ops[0] is validated; *e0 (the start event of a profiled group) goes to the first kernel enqueued here, if any.
+  // ws / ws_bytes: the caller's workspace (sqllm_launch_*_ws), used instead of an allocation when it is large enough.
+  int acquire(const sqllm_op* ops, int n, sqllm_stream_t stream, hipEvent_t* e0, void* ws, int64_t ws_bytes) {
+    s = static_cast<hipStream_t>(stream);
+    if (!ops[0].vec || ops[0].batch <= 0 || ops[0].K <= 0) return SQLLM_OK;
+    bool in_capture = false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (!(hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone)) {
+      (void)hipGetLastError();
+      in_capture = true;
     }
-    char* p = static_cast<char*>(block);
-    if (want_xT) {
+    char* p = nullptr;
+    Layout L = layout(ops, n, false);
+    if (ws && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0 && L.total() > 0 && (uint64_t)(ws_bytes > 0 ? ws_bytes : 0) >= L.total()) {
+      p = static_cast<char*>(ws);  // nothing allocated, nothing to free: a capture stays free of memory nodes
+    } else {
+      capturing = in_capture;
+      if (capturing && !knobs().scratch_in_capture.load(std::memory_order_relaxed)) return SQLLM_OK;
+      L = layout(ops, n, capturing);
+      if (L.total() == 0) return SQLLM_OK;
+      keep_scratch_in_pool();
+      if (hipMallocAsync(&block, L.total(), s) != hipSuccess || !block) {
+        (void)hipGetLastError();  // no scratch
+        block = nullptr;
+        return SQLLM_OK;
+      }
+      p = static_cast<char*>(block);
+    }
+    if (L.total() == 0) return SQLLM_OK;
+    if (L.xt) {
       xT = reinterpret_cast<float*>(p);
+      Bp = L.Bp;
       const hipError_t e = sqllm::transpose_vec(ops[0].vec, xT, ops[0].batch, ops[0].K, Bp, s, e0 ? *e0 : nullptr);
       if (e != hipSuccess) return static_cast<int>(e);  // (the destructor frees)
       if (e0) *e0 = nullptr;
-    } else {
-      Bp = 0;
     }
-    if (want_planes) {
-      planes = p + xt_bytes;
-      flags = reinterpret_cast<uint32_t*>(p + xt_bytes + plane_bytes);
-      if (slab_bytes) slabs = reinterpret_cast<float*>(p + xt_bytes + plane_bytes + flag_bytes);
+    if (L.planes) {
+      planes = p + L.xt;
+      flags = reinterpret_cast<uint32_t*>(p + L.xt + L.planes);
+      if (L.slabs) slabs = reinterpret_cast<float*>(p + L.xt + L.planes + L.flags);
       const hipError_t e = sqllm::split_vec(ops[0].vec, planes, flags, ops[0].batch, ops[0].K, s, e0 ? *e0 : nullptr);
       if (e != hipSuccess) return static_cast<int>(e);
       if (e0) *e0 = nullptr;
@@ -544,8 +617,9 @@ struct WideScratch {
 
 // One kernel over 1..kMaxSegments ops that share vec, K, bits and batch.  `lin` (optional) points at
 // the fused-linear descriptors the ops were taken from: `ops` is then lin[i].op.
+// `ws` / `ws_bytes`: the caller's workspace (sqllm_launch_*_ws; sqllm_workspace_bytes says how much a group can use), or null.
 static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t stream, hipEvent_t e0,
-                                    hipEvent_t e1, const sqllm_linear* lin = nullptr) {
+                                    hipEvent_t e1, const sqllm_linear* lin = nullptr, void* ws = nullptr, int64_t ws_bytes = 0) {
   if (n < 1 || n > sqllm::kMaxSegments) return SQLLM_E_GROUP;
   if (!ops && !lin) return SQLLM_E_NULL;
   // (small batches: a group whose summed columns pass the column-lane kernel's test takes that kernel as ONE launch --
@@ -584,8 +658,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
     return static_cast<int>(sqllm::launch_batched_cols(ops[0].bits, a, static_cast<hipStream_t>(stream)));
   }
-  if (!lin && takes_mfma_path(&ops[0]) && ops[0].batch <= sqllm::kSmallSplitRows && knobs().mfma_split.load(std::memory_order_relaxed) &&
-      knobs().mfma_fuse_small.load(std::memory_order_relaxed)) {
+  if (!lin && takes_small_split(&ops[0])) {
     // up to 16 rows on the split matrix-core kernel: ONE launch for the whole group, sparse roles included
     sqllm::LaunchArgs a;
     a.ev_start = e0;
@@ -594,6 +667,39 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     a.ga.n_seg = n;
     memset(a.ga.seg, 0, sizeof(a.ga.seg));
     int block = 0;
+    // The dense ranges are ONE round of workgroups, as many as the chip holds at once: the top-X slabs (8 per op, padded)
+    // take their slots from the same count.  (Planned beside them, 20-50 dense workgroups of a 13B launch found no slot,
+    // started when the first ones left and ran as a second round of their own: 34 instead of 22 us per down_proj launch at
+    // 16 rows -- profiles/r05_small_split_timeline.txt.)
+    // With a workspace: vec transposed first (xT[k][rows]: the folded CSR walk and the top-X slabs then read ONE line per
+    // k for all the batch rows); without, they gather from vec itself.
+    bool any_sparse = false;
+    for (int i = 0; i < n; ++i) any_sparse = any_sparse || (ops[i].nnz > 0 && ops[i].rows) || (ops[i].full_rows && ops[i].topX > 0);
+    const bool want_xT = any_sparse && ops[0].batch > 0 && ops[0].K > 0 && ops[0].vec && knobs().sparse_transpose.load(std::memory_order_relaxed);
+    const int64_t xt_bytes = want_xT ? sqllm::transpose_small_bytes(ops[0].batch, ops[0].K) : 0;
+    float* xT = nullptr;
+    struct Scratch {  // the workspace-less names: stream-ordered scratch, as for the wider batches (never inside a capture:
+      void* p = nullptr;  // its memory nodes cost more than the gathers -- profiles/r04_small_batch_layer.txt)
+      hipStream_t s = nullptr;
+      ~Scratch() { if (p) (void)hipFreeAsync(p, s); }
+    } own;
+    if (want_xT && ws && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0 && ws_bytes >= xt_bytes) {
+      xT = static_cast<float*>(ws);
+    } else if (want_xT) {
+      own.s = static_cast<hipStream_t>(stream);
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(own.s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+        keep_scratch_in_pool();
+        if (hipMallocAsync(&own.p, (size_t)xt_bytes, own.s) == hipSuccess && own.p) xT = static_cast<float*>(own.p);
+        else { (void)hipGetLastError(); own.p = nullptr; }
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    const bool with_xT = xT != nullptr;
+    int reserve = 0;
+    if (with_xT || knobs().small_reserve_topx.load(std::memory_order_relaxed))
+      for (int i = 0; i < n; ++i) reserve += (small_topx_blocks(&ops[i], with_xT, n) + 7) / 8 * 8;
     for (int i = 0; i < n; ++i) {
       const sqllm_op* op = &ops[i];
       int rc = validate(op);
@@ -603,30 +709,37 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       if ((uint64_t)op->batch * (uint64_t)op->K >= (1ull << 31)) return SQLLM_E_SHAPE;  // 32-bit row offsets into vec
       sqllm::Segment& sg = a.ga.seg[i];
       fill_segment(op, &sg);
-      make_plan_mfma(op, &sg.gm, n);
+      make_plan_mfma(op, &sg.gm, n, 0, small_wgs_per_cu_of(op), reserve);
+      sg.gm.topx_blocks = small_topx_blocks(op, with_xT, n);
+      fold_csr_into_dense(&sg.gm);
       a.ga.block0[i] = block;
       block += (sg.gm.dense_block0 + sg.gm.dense_blocks + 7) / 8 * 8;
     }
     for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
-    // (The CSR chunks gather from vec itself here.  Handing them a transposed copy -- WideScratch::xT, as the wider
-    // batches get -- was measured: no faster at 8 / 16 rows in the sum of the kernels (13B s45 layer 168 vs 155 us at 8
-    // rows), and inside a captured graph the scratch's allocation / free nodes cost ~25 us per group: 258 vs 150 us per
-    // layer.  profiles/r04_small_batch_layer.txt)
+    if (with_xT) {
+      if (knobs().sparse_transpose.load(std::memory_order_relaxed) != 2) {  // (2: TIMING EXPERIMENT ONLY -- the kernel reads whatever the workspace holds)
+        const hipError_t e = sqllm::transpose_small(ops[0].vec, xT, ops[0].batch, ops[0].K, static_cast<hipStream_t>(stream), e0);
+        if (e != hipSuccess) return static_cast<int>(e);
+        a.ev_start = nullptr;
+      }
+      a.xT = xT;
+    }
+    if (g_experimental.decorate) g_experimental.decorate(&a);  // (measurement library: timeline buffer)
     return static_cast<int>(sqllm::launch_small_split(ops[0].bits, a, static_cast<hipStream_t>(stream)));
   }
   if (!lin && (takes_mfma_path(&ops[0]) || (n == 1 && takes_cols_path(&ops[0])))) {
     // batched operators: one launch per op (the members of a group only share their input) of the
     // matrix-core kernel (wide batches) or of the column-lane kernel (small ones)
     const bool mfma = takes_mfma_path(&ops[0]);
-    WideScratch ws;  // (transposed vec for the CSR role, planes + slabs for the wide form: see the struct)
+    WideScratch wsc;  // (transposed vec for the CSR role, planes + slabs for the wide form: see the struct)
     if (mfma) {
       int rc = validate(&ops[0]);  // (its kernels read vec by batch and K: shape errors first)
       if (rc != SQLLM_OK) return rc;
-      rc = ws.acquire(ops, n, stream, &e0);
+      rc = wsc.acquire(ops, n, stream, &e0, ws, ws_bytes);
       if (rc != SQLLM_OK) return rc;
     }
-    float* const xT = ws.xT;
-    const int Bp = ws.Bp;
+    float* const xT = wsc.xT;
+    const int Bp = wsc.Bp;
     for (int i = 0; i < n; ++i) {
       const sqllm_op* op = &ops[i];
       int rc = validate(op);
@@ -641,9 +754,9 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       a.x = op->vec;
       a.xT = (op->nnz > 0 && op->rows && op->cols && op->vals) ? xT : nullptr;
       a.Bp = Bp;
-      a.planes = ws.planes;
-      a.plane_flags = ws.flags;
-      a.wide_slabs = ws.slabs;
+      a.planes = wsc.planes;
+      a.plane_flags = wsc.flags;
+      a.wide_slabs = wsc.slabs;
       a.ga.n_seg = 1;
       memset(a.ga.seg, 0, sizeof(a.ga.seg));
       sqllm::Segment& sg = a.ga.seg[0];
@@ -655,7 +768,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
       sg.vals = op->vals;
       sg.full_rows = op->topX > 0 ? op->full_rows : nullptr;
       sg.full_idx = op->topX > 0 ? op->full_row_indices : nullptr;
-      a.wide = mfma && takes_wide_path(op, ws.planes != nullptr, ws.capturing);
+      a.wide = mfma && takes_wide_path(op, wsc.planes != nullptr, wsc.capturing);
       if (a.wide) a.wide_full_units = make_plan_wide(op, &sg.gm);
       else if (mfma) make_plan_mfma(op, &sg.gm);
       else make_plan_cols(op, &sg.gm);
@@ -738,6 +851,8 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     // fused linear: a column's K slices + the CSR chunks its row can be spread over must fit the 6-bit count
     const int csr_bound = (op->rows && op->nnz > 0) ? op->K / sqllm::kCsrChunk + 2 : 0;
     make_plan(op, &sg.gm, n, lin ? (sqllm::kMaxContrib - csr_bound > 1 ? sqllm::kMaxContrib - csr_bound : 1) : sqllm::kMaxSlices);
+    // batch tiles of 2..8 rows: the CSR term is walked by the dense workgroups themselves (sqllm_fused.h: FOLDABLE)
+    if (!lin && sg.gm.batch >= 2 && sg.gm.nnz > 0 && knobs().csr_fold.load(std::memory_order_relaxed)) fold_csr_into_dense(&sg.gm);
     if (lin) {
       // accumulate into the workspace plane; op->mul is the fp16 result
       sg.y = reinterpret_cast<float*>(lin[i].workspace);
@@ -804,6 +919,41 @@ int sqllm_launch_groups(const sqllm_op* ops, const int32_t* group_sizes, int32_t
   return SQLLM_OK;
 }
 
+int64_t sqllm_workspace_bytes(const sqllm_op* ops, int32_t n_ops) {
+  if (!ops || n_ops < 1 || ops[0].batch < 2 || ops[0].K <= 0) return 0;  // (batch 1: one kernel, no scratch)
+  int64_t need = 0;
+  if (takes_small_split(&ops[0])) {
+    bool any_sparse = false;
+    for (int i = 0; i < n_ops; ++i) any_sparse = any_sparse || (ops[i].nnz > 0 && ops[i].rows) || (ops[i].full_rows && ops[i].topX > 0);
+    if (any_sparse && knobs().sparse_transpose.load(std::memory_order_relaxed)) need = sqllm::transpose_small_bytes(ops[0].batch, ops[0].K);
+  } else if (takes_mfma_path(&ops[0])) {
+    need = (int64_t)WideScratch::layout(ops, n_ops, false).total();
+  }
+  return (need + 255) / 256 * 256;
+}
+
+int sqllm_launch_ws(const sqllm_op* op, void* workspace, int64_t workspace_bytes, sqllm_stream_t stream) {
+  return launch_group_with_events(op, 1, stream, nullptr, nullptr, nullptr, workspace, workspace_bytes);
+}
+
+int sqllm_launch_group_ws(const sqllm_op* ops, int32_t n_ops, void* workspace, int64_t workspace_bytes, sqllm_stream_t stream) {
+  return launch_group_with_events(ops, n_ops, stream, nullptr, nullptr, nullptr, workspace, workspace_bytes);
+}
+
+int sqllm_launch_groups_ws(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups, void* workspace,
+                           int64_t workspace_bytes, sqllm_stream_t stream, int32_t* n_done) {
+  if (n_done) *n_done = 0;
+  if (n_groups < 0 || (n_groups > 0 && (!ops || !group_sizes))) return SQLLM_E_NULL;
+  int32_t at = 0;
+  for (int32_t g = 0; g < n_groups; ++g) {
+    int rc = launch_group_with_events(ops + at, group_sizes[g], stream, nullptr, nullptr, nullptr, workspace, workspace_bytes);
+    if (rc != SQLLM_OK) return rc;
+    at += group_sizes[g];
+    if (n_done) *n_done = g + 1;
+  }
+  return SQLLM_OK;
+}
+
 int sqllm_launch_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t stream, int32_t* n_done) {
   if (n_done) *n_done = 0;
   if (n_ops < 0 || (n_ops > 0 && !ops)) return SQLLM_E_NULL;
@@ -817,6 +967,11 @@ int sqllm_launch_sequence(const sqllm_op* ops, int32_t n_ops, sqllm_stream_t str
 
 int sqllm_profile_groups(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups,
                          sqllm_stream_t stream, int32_t reps, float* avg_us) {
+  return sqllm_profile_groups_ws(ops, group_sizes, n_groups, nullptr, 0, stream, reps, avg_us);
+}
+
+int sqllm_profile_groups_ws(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups, void* workspace,
+                            int64_t workspace_bytes, sqllm_stream_t stream, int32_t reps, float* avg_us) {
   if (n_groups < 0 || reps < 1 || (n_groups > 0 && (!ops || !group_sizes || !avg_us))) return SQLLM_E_NULL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipEvent_t* ev = new hipEvent_t[2 * (size_t)n_groups + 1];
@@ -828,7 +983,7 @@ int sqllm_profile_groups(const sqllm_op* ops, const int32_t* group_sizes, int32_
   for (int r = 0; r < reps && rc == SQLLM_OK; ++r) {
     int32_t at = 0;
     for (int g = 0; g < n_groups && rc == SQLLM_OK; ++g) {
-      rc = launch_group_with_events(ops + at, group_sizes[g], stream, ev[2 * g], ev[2 * g + 1]);
+      rc = launch_group_with_events(ops + at, group_sizes[g], stream, ev[2 * g], ev[2 * g + 1], nullptr, workspace, workspace_bytes);
       at += group_sizes[g];
     }
     if (rc != SQLLM_OK) break;

@@ -312,6 +312,18 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
       for (int i = 0; i < RPW; ++i) ev[i] = src[2 * (st_h * RPW + i) + (lane >> 5)];
     }
   }
+  // Batch tiles of an operator launch whose plan folds the CSR term into the dense workgroups (gm.fold_csr, 2-8 rows;
+  // csr_tile_fold, sqllm_roles.h): the tile's 65 row pointers are staged with the codebooks -- an UNCONDITIONAL load
+  // (see below), thread t fetches pointer t % 128 (without the term: the codebook pointer).
+  constexpr bool FOLDABLE = BT > 1 && std::is_same<XT, float>::value;
+  bool fold_csr = false;
+  int rpv = 0;
+  if constexpr (FOLDABLE) {
+    fold_csr = sg.gm.fold_csr != 0;
+    int rc = col0 + (tid & (kFoldRp - 1));
+    if (rc > N) rc = N;
+    rpv = (fold_csr ? sg.rows : reinterpret_cast<const int*>(lut))[fold_csr ? rc : 0];
+  }
   // Fused linear: the top-X rows are folded into the dense tiles.  The first 64 column indices go
   // out first (consumed right after the staging barrier, while the weight loads behind them are
   // still in flight).  The load is UNCONDITIONAL -- without top-X rows it reads the codebook
@@ -366,6 +378,9 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
       for (int i = 0; i < RPW; ++i) dst[2 * (st_h * RPW + i) * (ESTRIDE / 4)] = ev[i];
     }
   }
+
+  int* srp = reinterpret_cast<int*>(topx_sum + BT * kTileN);  // FOLDABLE: the tile's row pointers
+  if constexpr (FOLDABLE) srp[tid & (kFoldRp - 1)] = rpv;
 
   f32x2 acc[2][BT];  // [column pair][batch row]: columns 2p and 2p+1 of the lane's four
 #pragma unroll
@@ -454,11 +469,16 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
   if (tl && lane == 0) tl[4 + (wave & 3)] = __builtin_amdgcn_s_memrealtime();  // decode end of waves 0-3
 #endif
+  if constexpr (FOLDABLE) {
+    // the CSR rows of this tile, this slice's share: sums into topx_sum ([BT][64], zeroed above), which the combining
+    // wave adds to the column sums (every wave's LDS adds precede its ticket)
+    if (fold_csr) csr_tile_fold<WAVES * 64>(x, sg.cols, sg.vals, K, b0, nb, u_beg, u_end, units_total, srp, topx_sum, tid);
+  }
   if constexpr (PAIR) {
     acc[0][0] = f32x2{accp[0].x + accp[0].y, accp[1].x + accp[1].y};
     acc[1][0] = f32x2{accp[2].x + accp[2].y, accp[3].x + accp[3].y};
   }
-  dense_epilogue<BT, WAVES, ABL>(acc, lds + kCodebookFloats, topx_sum, fold_topx, y, N, col0, b0, nb, lane, wave, sg, lin
+  dense_epilogue<BT, WAVES, ABL>(acc, lds + kCodebookFloats, topx_sum, fold_topx || fold_csr, y, N, col0, b0, nb, lane, wave, sg, lin
 #ifdef SQLLM_ABLATION_BUILD
                                  , tl
 #endif

@@ -790,6 +790,32 @@ __global__ void __launch_bounds__(256) sqllm_transpose_vec(const float* __restri
   }
 }
 
+// Small batches (2..16 rows): xT[k][rp], rp = the batch rounded up to a power of two, rows past the batch zero -- one
+// thread per k, coalesced reads along k, one 8..64-byte store.  Read by the folded CSR walk (csr_tile_fold_staged).
+__global__ void __launch_bounds__(256) sqllm_transpose_small(const float* __restrict__ x, float* __restrict__ xT, int batch, int K, int lr) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const int rp = 1 << lr;
+  float v[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) v[b] = (b < batch && b < rp) ? x[(size_t)b * K + k] : 0.f;
+  float* dst = xT + ((size_t)k << lr);
+  if (rp == 2) {
+    *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (4 * q < rp) *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+  }
+}
+
+hipError_t transpose_small(const float* x, float* xT, int batch, int K, hipStream_t stream, hipEvent_t ev_start) {
+  const int lr = batch <= 2 ? 1 : batch <= 4 ? 2 : batch <= 8 ? 3 : 4;
+  if (ev_start) hipExtLaunchKernelGGL(sqllm_transpose_small, dim3((K + 255) / 256), dim3(256), 0, stream, ev_start, nullptr, 0, x, xT, batch, K, lr);
+  else hipLaunchKernelGGL(sqllm_transpose_small, dim3((K + 255) / 256), dim3(256), 0, stream, x, xT, batch, K, lr);
+  return hipGetLastError();
+}
+
 hipError_t transpose_vec(const float* x, float* xT, int batch, int K, int Bp, hipStream_t stream, hipEvent_t ev_start) {
   if (ev_start) hipExtLaunchKernelGGL(sqllm_transpose_vec, dim3((K + 63) / 64, Bp / 64), dim3(256), 0, stream, ev_start, nullptr, 0, x, xT, batch, K, Bp);
   else hipLaunchKernelGGL(sqllm_transpose_vec, dim3((K + 63) / 64, Bp / 64), dim3(256), 0, stream, x, xT, batch, K, Bp);

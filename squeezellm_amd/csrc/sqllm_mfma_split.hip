@@ -42,16 +42,29 @@
 #include "sqllm_decode.h"
 #include "sqllm_roles.h"
 #include "sqllm_split_common.h"
+#include "sqllm_probe.h"
 
 namespace sqllm {
 
 namespace {
 
-template <int BITS, int MB, int WAVES>
+// FOLD: the op's CSR term is walked by these workgroups themselves (csr_tile_fold, sqllm_roles.h; MB == 1 only):
+// csr_rows / csr_cols / csr_vals are the op's CSR (csr_rows null: no such term), LDS grows by the sums, the tile's row
+// pointers and a ticket word.  ONE wave of the workgroup (the last) walks the piece's share of the tile's non-zeros
+// while the other seven decode: the walk is a chain of round trips (columns -> gathers of vec, one cache line per
+// non-zero and batch row) with next to no arithmetic, and beside the dense loop it costs that wave's issue slots only.
+// So that nobody waits for the walker, the groups of a piece are handed out through an LDS ticket (the first seven
+// statically): when it is done it draws tickets like everybody else.
+template <int BITS, int MB, int WAVES, bool FOLD = false>
 __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ x, const u32x4* __restrict__ q,
                                                       float* __restrict__ y, const float* __restrict__ lut, int K, int N,
                                                       int batch, int m0, int bid, int n_col_tiles, int units_total,
-                                                      int units_per_wg, int units_stride, float* lds) {
+                                                      int units_per_wg, int units_stride, float* lds,
+                                                      const int* __restrict__ csr_rows = nullptr, const int* __restrict__ csr_cols = nullptr,
+                                                      const float* __restrict__ csr_vals = nullptr, const float* __restrict__ xT = nullptr,
+                                                      unsigned long long* tl = nullptr) {
+  static_assert(!FOLD || MB == 1, "the folded CSR walk serves one block of 16 rows");
+  static_assert(!FOLD || WAVES * 16 * 64 >= 2 * kFoldStage, "the walk stages columns and values in the slab area");
   constexpr int XMODE = 0;  // vec = fp32 rows, split in registers
   constexpr int NX = 2 * MB;  // 16-byte registers of one phase's vec values
   using F = Fmt<BITS>;
@@ -60,11 +73,18 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
   constexpr int T = WAVES * 64;
   __builtin_amdgcn_s_waitcnt(0);  // clean slate for the compiler's wait-count model (see dense_role)
   const int tid = threadIdx.x;
+  SQLLM_PROBE_ENTRY(tl, tid == 0);  // entry (+ where: XCC, CU)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, grp = lane >> 4;
   constexpr int kCbBytes = split_codebook_bytes(BITS);
   float* slabs = lds + kCbBytes / 4;
+  float* ssum = slabs + WAVES * 16 * 64;                   // FOLD: [16][64] sums of the CSR walk (zero between pieces)
+  int* srp = reinterpret_cast<int*>(ssum + kFoldSum);      // FOLD: the tile's row pointers
+  const bool fold = FOLD && csr_rows != nullptr;
+  if constexpr (FOLD) {
+    for (int i = tid; i < kFoldSum; i += T) ssum[i] = 0.f;  // (visible after the first piece's staging barrier)
+  }
   const int row_stride = N / 4;  // in 16-byte units
   const char* qbase = reinterpret_cast<const char*>(q);
   const uint32_t row_bytes = 16u * (uint32_t)row_stride;
@@ -104,13 +124,19 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
     if (c > N - 1) c = N - 1;
     ev[i] = lut[(size_t)c * L + (row % L)];
   }
+  int rpv = 0;
+  if constexpr (FOLD) {  // row pointer (tid % 128) of the tile, clamped at N: an unconditional load beside the codebook's
+    int rc = col0 + (tid & (kFoldRp - 1));
+    if (rc > N) rc = N;
+    rpv = (fold ? csr_rows : reinterpret_cast<const int*>(lut))[fold ? rc : 0];
+  }
   const int n_groups_wg = (u_end - u_beg + 3) / 4;
   const int n_g = n_groups_wg > wave ? (n_groups_wg - wave + WAVES - 1) / WAVES : 0;
   int cidx = col0 / 4 + i16;
   if (cidx > row_stride - 1) cidx = row_stride - 1;
   const uint32_t lane_bytes = 16u * (uint32_t)cidx;
-  auto group_unit = [&](int g) {  // unit of this lane's row in the wave's group g (may be >= u_end)
-    return u_beg + 4 * (wave + WAVES * g) + grp;
+  auto group_unit = [&](int t) {  // unit of this lane's row in group t of the piece (may be >= u_end)
+    return u_beg + 4 * t + grp;
   };
   auto clamp_unit = [&](int u) {
     if (u > u_end - 1) u = u_end - 1;  // clamped re-read inside the slice; its x values are zeroed
@@ -134,8 +160,8 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
   };
   u32x4 wa[R], wb[R];
   u32x4 xa[NX], xb[NX];
-  load_w(0, wa);
-  load_x(0, 0, xa);
+  load_w(wave, wa);
+  load_x(wave, 0, xa);
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   // ---- stage the codebooks, split ----
@@ -145,6 +171,7 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
     for (int i = 0; i < NST; ++i) {
       *reinterpret_cast<u32x2*>(base + 8 * (tid + T * i)) = split_entry(ev[i]);
     }
+    if constexpr (FOLD) srp[tid & (kFoldRp - 1)] = rpv;
   }
   f32x4 acc[MB][4];
 #pragma unroll
@@ -152,6 +179,37 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();  // codebooks staged (and everybody has left the previous piece's slabs)
+  SQLLM_PROBE(tl, 1, tid == 0);  // codebooks staged
+  // FOLD: this piece's share of the tile's non-zeros, and the first kFoldPre columns / values per thread on their way
+  constexpr int kFoldPre = 3;
+  int sp_beg = 0, sp_end = 0;
+  int pre_c[kFoldPre];
+  float pre_v[kFoldPre];
+  unsigned pre_r = 0;
+  if constexpr (FOLD) {
+    if (fold) {
+      fold_piece_share(srp, u_beg, u_end, units_total, &sp_beg, &sp_end);
+      sp_beg = __builtin_amdgcn_readfirstlane(sp_beg);
+      sp_end = __builtin_amdgcn_readfirstlane(sp_end);
+    }
+    {  // their CSR rows (local to the tile), six bits each
+      int ea[kFoldPre], rr[kFoldPre];
+#pragma unroll
+      for (int i = 0; i < kFoldPre; ++i) ea[i] = sp_beg + tid + T * i;
+      fold_rows_of<kFoldPre>(srp, ea, rr);
+#pragma unroll
+      for (int i = 0; i < kFoldPre; ++i) pre_r |= (unsigned)rr[i] << (6 * i);
+    }
+#pragma unroll
+    for (int i = 0; i < kFoldPre; ++i) {
+      int ee = sp_beg + tid + T * i;
+      if (ee > sp_end - 1) ee = sp_end - 1;
+      if (ee < 0) ee = 0;
+      // (unconditional loads -- see the codebook's; without the term: the codebook pointer)
+      pre_c[i] = (fold ? csr_cols : reinterpret_cast<const int*>(lut))[fold ? ee : 0];
+      pre_v[i] = (fold ? csr_vals : lut)[fold ? ee : 0];
+    }
+  }
 
   auto phase = [&](const u32x4 (&t)[R], auto ph_tag, const u32x4 (&dx)[NX], int g) {
     split_phase<BITS, MB, XMODE, decltype(ph_tag)::value>(t, dx, group_unit(g) < u_end, lane_off, 0u, acc);
@@ -160,13 +218,13 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
   using P1 = std::integral_constant<int, 1>;
   using P2 = std::integral_constant<int, 2>;
   using P3 = std::integral_constant<int, 3>;
-  // decode group g out of (w, xcur = its phase-0 vec values); the NEXT group's weights (into wn) are loaded before the
-  // first phase, its phase-0 values (into xn) before the last.  With four phases the values of phase p + 1 are loaded
-  // while phase p runs, alternating between xcur and xo -- the next group's phase 0 lands in xcur again (xn == xcur).
-  auto decode_group = [&](int g, const u32x4 (&w)[R], u32x4 (&xcur)[NX], u32x4 (&wn)[R], u32x4 (&xn)[NX], u32x4 (&xo)[NX]) {
-    load_w(g + 1, wn);
+  // decode group g out of (w, xcur = its phase-0 vec values); the wave's NEXT group gn: its weights (into wn) are loaded
+  // before the first phase, its phase-0 values (into xn) before the last.  With four phases the values of phase p + 1 are
+  // loaded while phase p runs, alternating between xcur and xo -- the next group's phase 0 lands in xcur again (xn == xcur).
+  auto decode_group = [&](int g, int gn, const u32x4 (&w)[R], u32x4 (&xcur)[NX], u32x4 (&wn)[R], u32x4 (&xn)[NX], u32x4 (&xo)[NX]) {
+    load_w(gn, wn);
     if constexpr (NPH == 1) {
-      load_x(g + 1, 0, xn);
+      load_x(gn, 0, xn);
       __builtin_amdgcn_sched_barrier(0);
       phase(w, P0{}, xcur, g);
     } else {
@@ -179,22 +237,30 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
       load_x(g, 3, xo);
       __builtin_amdgcn_sched_barrier(0);
       phase(w, P2{}, xcur, g);
-      load_x(g + 1, 0, xn);
+      load_x(gn, 0, xn);
       __builtin_amdgcn_sched_barrier(0);
       phase(w, P3{}, xo, g);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  for (int g = 0; g < n_g; g += 2) {
+  for (int g = 0; g < n_g; g += 2) {  // the wave's groups: wave, wave + WAVES, ...
+    const int t = wave + WAVES * g;
     if constexpr (NPH == 1) {
-      decode_group(g, wa, xa, wb, xb, xb);
-      decode_group(g + 1, wb, xb, wa, xa, xa);
+      decode_group(t, t + WAVES, wa, xa, wb, xb, xb);
+      decode_group(t + WAVES, t + 2 * WAVES, wb, xb, wa, xa, xa);
     } else {
-      decode_group(g, wa, xa, wb, xa, xb);
-      decode_group(g + 1, wb, xa, wa, xa, xb);
+      decode_group(t, t + WAVES, wa, xa, wb, xa, xb);
+      decode_group(t + WAVES, t + 2 * WAVES, wb, xa, wa, xa, xb);
     }
   }
-
+  SQLLM_PROBE(tl, 2, tid == 0);  // wave 0 done decoding
+  SQLLM_PROBE(tl, 7, tid == T - 64);  // the last wave done decoding
+  if constexpr (FOLD) {
+    if (fold)
+      csr_tile_fold_staged<T, 20, kFoldPre>(x, xT, csr_cols, csr_vals, K, m0, batch - m0 < 16 ? batch - m0 : 16, sp_beg, sp_end, srp, ssum,
+                                           reinterpret_cast<int*>(slabs), tid, pre_c, pre_v, pre_r, tl);
+  }
+  SQLLM_PROBE(tl, 5, tid == 0);  // CSR share walked (all waves)
   // ---- waves meet in LDS, one row block at a time (see dense_role_mfma) ----
   float* slab = slabs + wave * (16 * 64) + (4 * grp) * 64 + 4 * i16;
 #pragma unroll
@@ -212,9 +278,15 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
       float sum = 0.f;
 #pragma unroll
       for (int w = 0; w < WAVES; ++w) sum += slabs[w * (16 * 64) + e];
+      if constexpr (FOLD) {  // the CSR walk's sums; zero again for the next piece (this thread is the element's only reader)
+        const int se = (e >> 6) * kFoldSumStride + (e & 63);
+        sum += ssum[se];
+        ssum[se] = 0.f;
+      }
       if (r < batch && col < N) acc_add(y + (size_t)r * N + col, sum);
     }
   }
+  SQLLM_PROBE(tl, 6, tid == 0);  // atomics issued
   }  // pieces
 }
 
@@ -277,21 +349,24 @@ sqllm_fused_batched_split_all(const float* x, const GroupArgs ga, const float* x
 }
 
 // ------------------------------------------------------------------------------------------------
-// Up to 16 rows: ONE launch for 1..kMaxSegments ops over one vec, all three terms -- the grid of the batch-1 fused
-// kernel (per op [CSR chunks | top-X slabs | pad to x8 | dense ranges]) with the split matrix-core role as its dense
-// role.  (From 17 rows on the sparse terms are a launch of their own, as for the fp32 kernel: sqllm_sparse_batched.)
-// The reference runs 1-3 dependent launches per op and one weight pass per batch row
+// Up to 16 rows: ONE launch for 1..kMaxSegments ops over one vec, all three terms -- per op [top-X slabs | pad to x8 |
+// dense ranges], the split matrix-core role as the dense role, and the CSR term FOLDED into it (csr_tile_fold,
+// sqllm_roles.h: every dense workgroup walks the non-zeros of its own 64 output channels; gm.fold_csr, gm.csr_blocks == 0).
+// Until round 5 the CSR term was a role of its own here (one workgroup per 1024 non-zeros, first in the grid): with its
+// LDS (68 KB) and registers (106) the kernel held two workgroups per CU, the chunk workgroups took the whole first round
+// of slots for their chain of dependent round trips, and a 13B s45 decoder layer paid 50 us for them at 8 rows, 80 at 16
+// (profiles/r04_small_batch_layer.txt).  Now: 53 KB and <= 80 registers at 4 bits, three workgroups per CU.
+// (From 17 rows on the sparse terms are workgroups in the grid or a launch of their own: sqllm_fused_batched_split_all,
+// sqllm_sparse_batched.)  The reference runs 1-3 dependent launches per op and one weight pass per batch row
 // (squeezellm/quant_cuda_kernel.cu:580-657, :661-738).
 // ------------------------------------------------------------------------------------------------
 constexpr int kSmallRows = 16;
 
 template <int BITS, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, 4)
-sqllm_fused_small_split(const float* x, const GroupArgs ga, const float* xT, int Bp) {
+sqllm_fused_small_split(const float* x, const GroupArgs ga, const float* xT) {
   constexpr int T = WAVES * 64;
-  // (the transposed-vec CSR role lays its LDS out for up to 64 rows: sqllm_roles.h, csr_role XTMODE)
-  __shared__ __attribute__((aligned(16))) float lds[cmax(split_lds_floats(BITS, WAVES),
-                                                         cmax(kCsrSpanMax + cmax(kCsrSpanMax, 64 * (kCsrXtSpan + 1) + 3 * kCsrChunk), kTopxLds))];
+  __shared__ __attribute__((aligned(16))) float lds[cmax(split_lds_floats(BITS, WAVES) + kFoldSum + kFoldRp, kTopxLds)];
   // one round of scalar loads for the block table and segment 0 (see sqllm_fused_matvec)
   Segment sg = ga.seg[0];
   const int n_seg = ga.n_seg, blk1 = ga.block0[1], blk2 = ga.block0[2], blk3 = ga.block0[3];
@@ -310,17 +385,25 @@ sqllm_fused_small_split(const float* x, const GroupArgs ga, const float* xT, int
   const int bid = blockIdx.x - base;
   const int d = bid - gm.dense_block0;
   if (d >= 0 && d < gm.dense_blocks) {
-    dense_role_mfma_split<BITS, 1, WAVES>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, gm.batch, 0, d, gm.col_tiles,
-                                          gm.units_total, gm.units_per_wg,
-                                          gm.dense_blocks == gm.col_tiles * gm.k_slices ? gm.k_slices * gm.units_per_wg : gm.units_total, lds);
-  } else if (bid < gm.csr_blocks) {
-    // vec transposed (xT[k][row], written by sqllm_transpose_vec just before this launch): ONE 64-byte read per non-zero
-    // serves all the rows; without scratch, gathers from vec itself, one per non-zero and row
-    if (xT) csr_role<T, 1, float, float, true>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, 0, gm.batch, bid, lds, nullptr, 0, xT, Bp);
-    else if (gm.batch > 8) csr_role<T, kSmallRows, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, 0, gm.batch, bid, lds, nullptr, 0);
-    else csr_role<T, 8, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, 0, gm.batch, bid, lds, nullptr, 0);  // (the role gathers and loops for its full tile of rows)
-  } else if (bid < gm.csr_blocks + gm.topx_blocks) {
-    topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, 0, gm.batch, bid - gm.csr_blocks, lds);
+    dense_role_mfma_split<BITS, 1, WAVES, true>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, gm.batch, 0, d, gm.col_tiles,
+                                                gm.units_total, gm.units_per_wg,
+                                                gm.dense_blocks == gm.col_tiles * gm.k_slices ? gm.k_slices * gm.units_per_wg : gm.units_total, lds,
+                                                gm.nnz > 0 ? sg.rows : nullptr, sg.cols, sg.vals, xT, SQLLM_PROBE_PTR(sg));
+  } else if (bid < gm.topx_blocks) {
+    // top-X slabs: gm.topx_blocks workgroups share the op's ceil(K / kTopxRows) slabs (with the transposed vec: 8-16
+    // workgroups of several slabs each, all batch rows at once; without: one slab each, passes of 8 rows)
+    const int slabs = (gm.K + kTopxRows - 1) / kTopxRows;
+    const int spw = (slabs + gm.topx_blocks - 1) / gm.topx_blocks;
+    const int s0 = bid * spw, s1 = s0 + spw < slabs ? s0 + spw : slabs;
+    if (xT && gm.topX <= 16) {
+      const int lr = gm.batch <= 2 ? 1 : gm.batch <= 4 ? 2 : gm.batch <= 8 ? 3 : 4;
+      if (s0 < s1) topx_role_xt<T>(xT, lr, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, gm.batch, s0, s1, lds);
+    } else {
+      for (int sl = s0; sl < s1; ++sl) {
+        if (sl > s0) __syncthreads();
+        topx_role<T, float, float, false, NoGate, 8>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, 0, gm.batch, sl, lds);
+      }
+    }
   }
 }
 
@@ -375,12 +458,12 @@ hipError_t launch_small_split(int bits, const LaunchArgs& a, hipStream_t stream)
   const float* x = static_cast<const float*>(a.x);
   if (bits == 4) {
     auto kern = sqllm_fused_small_split<4, kWaves>;
-    if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga, a.xT, a.Bp);
-    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga, a.xT, a.Bp);
+    if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga, a.xT);
+    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga, a.xT);
   } else {
     auto kern = sqllm_fused_small_split<3, kWaves>;
-    if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga, a.xT, a.Bp);
-    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga, a.xT, a.Bp);
+    if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga, a.xT);
+    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga, a.xT);
   }
   return hipGetLastError();
 }

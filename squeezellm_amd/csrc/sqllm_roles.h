@@ -4,6 +4,7 @@
 // :1092-1164 (DenseMatVecKernel[Batched]).
 #pragma once
 #include "sqllm_decode.h"
+#include "sqllm_probe.h"
 
 namespace sqllm {
 
@@ -488,11 +489,261 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
 }
 
 // ------------------------------------------------------------------------------------------------
+// CSR rows FOLDED into the dense workgroups (small batches, 2..16 rows; replaces SPMV_ATOMIC_BATCHED,
+// squeezellm/quant_cuda_kernel.cu:1061-1089, for those).  CSR rows are output channels, so the non-zeros of
+// a 64-column dense tile are ONE contiguous range of cols / vals, rows[col0] .. rows[col0 + 64); the
+// workgroups that share the tile (its K slices) cut that range in proportion to their units of K, and each
+// walks its share itself, after its dense loop: the sums meet the dense partial sums in LDS and leave in the
+// tile's own epilogue.  No chunk workgroups (each of them 4-8 us of dependent memory round trips in a slot a
+// dense workgroup could hold: with two or three 512-thread workgroups per CU they were the first round of
+// the grid and cost a 13B s45 decoder layer 50 us at 8 rows, 80 at 16), no global atomics of their own, no
+// row search over rows[] (the tile's 65 row pointers are staged with the codebooks).
+//
+// The walk: lane = (group, batch row); a group of R lanes (R = the batch rounded up to a power of two) takes
+// a contiguous run of the share and walks it one non-zero per step -- column and value are read by all R
+// lanes (one address), x[row][column] is a gather per lane, the running sum leaves with ONE LDS add per
+// (CSR row, batch row) when the run crosses into the next row.  The cost of a non-zero does not depend on
+// the batch (the segmented scan of csr_role cost ~30 dependent instructions per batch row and run).
+//   srp   LDS, rows[min(col0 + i, N)] for i = 0 .. 64 (staged by the caller, visible)
+//   ssum  LDS [16][64] floats, zero: sums by (batch row, local column) -- the layout of an epilogue slab
+// ------------------------------------------------------------------------------------------------
+constexpr int kFoldRp = 128;   // staged row pointers (65 used; thread t stores entry t % 128)
+constexpr int kFoldSumStride = kTileN + 1;  // floats between the batch rows of the sums: a group's lanes (one batch row each) add to different banks
+constexpr int kFoldSum = 16 * kFoldSumStride;
+
+// share of a tile's non-zeros [0, len) that belongs to units [0, u) of `units_total`: monotone, f(units_total) = len
+__device__ __forceinline__ int fold_share(int len, int u, int units_total, unsigned inv) {
+  return u >= units_total ? len : (int)__umulhi((unsigned)len, (unsigned)u * inv);
+}
+
+template <int T, int U = 8>  // T: threads of the team that walks (tid = 0 .. T - 1), U: non-zeros in flight per lane
+__device__ __forceinline__ void csr_tile_fold(const float* __restrict__ x, const int* __restrict__ cols,
+                                              const float* __restrict__ vals, int K, int b0, int nb, int u_beg,
+                                              int u_end, int units_total, const int* srp, float* ssum, int tid) {
+  const int lo = srp[0];
+  const int len = srp[kTileN] - lo;
+  if (len <= 0) return;
+  const unsigned inv = 0xFFFFFFFFu / (unsigned)units_total;
+  const int sbeg = lo + fold_share(len, u_beg, units_total, inv);
+  const int send = lo + fold_share(len, u_end, units_total, inv);
+  const int n = send - sbeg;
+  if (n <= 0) return;
+  const int lr = nb <= 2 ? 1 : nb <= 4 ? 2 : nb <= 8 ? 3 : 4;  // log2 of the lanes per group
+  const int per = (n + (T >> lr) - 1) >> (__builtin_ctz(T) - lr);  // non-zeros per group, T >> lr groups
+  const int bl = tid & ((1 << lr) - 1);
+  int e = sbeg + (tid >> lr) * per;
+  int g_hi = e + per;
+  if (g_hi > send) g_hi = send;
+  if (e >= g_hi) return;
+  // the CSR row of the run's first non-zero: the largest r with srp[r] <= e
+  int r = 0;
+#pragma unroll
+  for (int s = kTileN / 2; s > 0; s >>= 1)
+    if (srp[r + s] <= e) r += s;
+  int rend = srp[r + 1];
+  const bool live = bl < nb;
+  const float* xl = x + (size_t)(b0 + (live ? bl : nb - 1)) * K;
+  float* srow = ssum + bl * kTileN;
+  float acc = 0.f;
+  // columns and values of a batch are loaded beside the gathers of the batch before (one round trip per batch)
+  int c[U];
+  float v[U];
+  auto load_cv = [&](int e0, int (&cc)[U], float (&vv)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ee = e0 + u < g_hi ? e0 + u : g_hi - 1;  // (clamped re-reads; skipped below)
+      cc[u] = cols[ee];
+      vv[u] = vals[ee];
+    }
+  };
+  load_cv(e, c, v);
+  for (; e < g_hi; e += U) {
+    float xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) xv[u] = xl[c[u]];
+    int c2[U];
+    float v2[U];
+    load_cv(e + U, c2, v2);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int eu = e + u;
+      if (eu < g_hi) {
+        if (eu >= rend) {  // the run enters another row (empty rows in between are skipped)
+          if (live) atomicAdd(srow + r, acc);
+          acc = 0.f;
+          do {
+            ++r;
+            rend = srp[r + 1];
+          } while (eu >= rend && r < kTileN - 1);
+        }
+        acc = __builtin_fmaf(v[u], xv[u], acc);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      c[u] = c2[u];
+      v[u] = v2[u];
+    }
+  }
+  if (live) atomicAdd(srow + r, acc);
+}
+
+// The same walk for a whole workgroup with the share's columns and values STAGED in LDS first (the fused small launch of
+// the split matrix-core kernel, after its dense loop): one coalesced round of loads for all of them -- the first PRE per
+// thread may have been loaded before the dense loop (pre_c / pre_v: element tid + T i of the share, clamped re-reads past
+// it) -- then every group gathers U values of vec per round trip.  Every thread of the workgroup must call it (barriers).
+//   stage  LDS, 2 * kFoldStage words, free until the caller's epilogue (its cross-wave slabs)
+constexpr int kFoldStage = 4096;  // non-zeros staged per pass
+
+// the share [sbeg, send) of this piece in the tile's non-zeros (absolute indices into cols / vals)
+__device__ __forceinline__ void fold_piece_share(const int* srp, int u_beg, int u_end, int units_total, int* sbeg, int* send) {
+  const int lo = srp[0];
+  int len = srp[kTileN] - lo;
+  if (len < 0) len = 0;
+  const unsigned inv = 0xFFFFFFFFu / (unsigned)units_total;
+  *sbeg = lo + fold_share(len, u_beg, units_total, inv);
+  *send = lo + fold_share(len, u_end, units_total, inv);
+}
+
+//   xT     vec TRANSPOSED for this pass of rows, xT[k][2^lr] (sqllm_transpose_small; rows past the batch zero), or null:
+//          a group's lanes then read ONE line per non-zero; gathers from vec itself cost a line per non-zero AND batch row
+//          (~2.5 cycles of the CU's vector memory pipe each: 46 / 100 us of a 13B s45 decoder layer at 8 / 16 rows,
+//          profiles/r05_fold_staged_gathers.txt)
+// local rows of N non-zeros (absolute indices ea[]): the largest r with srp[r] <= ea, the N searches side by side
+template <int N>
+__device__ __forceinline__ void fold_rows_of(const int* srp, const int (&ea)[N], int (&r)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = 0;
+#pragma unroll
+  for (int s = kTileN / 2; s > 0; s >>= 1) {
+    int p[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = srp[r[i] + s];
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] += p[i] <= ea[i] ? s : 0;
+  }
+}
+
+// pre_r: the local rows of the preloaded non-zeros, six bits each (fold_rows_of, worked out before the dense loop as well)
+template <int T, int U, int PRE>
+__device__ __forceinline__ void csr_tile_fold_staged(const float* __restrict__ x, const float* __restrict__ xT, const int* __restrict__ cols,
+                                                     const float* __restrict__ vals, int K, int b0, int nb, int sbeg, int send,
+                                                     const int* srp, float* ssum, int* stage, int tid, const int (&pre_c)[PRE],
+                                                     const float (&pre_v)[PRE], unsigned pre_r, unsigned long long* tl = nullptr) {
+  // staged per non-zero: its column with its LOCAL CSR ROW in the top six bits (K < 2^26: the host routes wider
+  // matrices elsewhere), and its value.  With the row at hand the walk has no search, no dependent read and no loop
+  // at a row boundary: a step is compare / masked LDS add / select / FMA.  (The first version tracked the row end
+  // with a data-dependent loop inside every step: ~45 instructions per step, 14 us of a 13B gate/up launch at 16 rows.)
+  int* scol = stage;
+  float* sval = reinterpret_cast<float*>(stage + kFoldStage);
+  const int lr = nb <= 2 ? 1 : nb <= 4 ? 2 : nb <= 8 ? 3 : 4;  // log2 of the lanes per group
+  const int bl = tid & ((1 << lr) - 1);
+  const bool live = bl < nb;
+  const float* xl = xT ? xT + bl : x + (size_t)(b0 + (live ? bl : nb - 1)) * K;
+  const int csh = xT ? lr : 0;  // a column's offset: col << csh
+  float* srow = ssum + bl * kFoldSumStride;
+  for (int p0 = sbeg; p0 < send; p0 += kFoldStage) {  // (workgroup-uniform)
+    const int np = send - p0 < kFoldStage ? send - p0 : kFoldStage;
+    // ---- stage the pass's columns (+ rows) and values ----
+    if (p0 == sbeg) {
+#pragma unroll
+      for (int i = 0; i < PRE; ++i) {
+        if (tid + T * i < np) {
+          scol[tid + T * i] = pre_c[i] | (((pre_r >> (6 * i)) & 63) << 26);
+          sval[tid + T * i] = pre_v[i];
+        }
+      }
+    }
+    for (int i0 = (p0 == sbeg ? PRE * T : 0); i0 < np; i0 += 4 * T) {
+      int cc[4];
+      float vv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * T + tid;
+        const int ii = i < np ? i : np - 1;
+        cc[k] = cols[p0 + ii];
+        vv[k] = vals[p0 + ii];
+      }
+      int ea[4], rr[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ea[k] = p0 + i0 + k * T + tid;
+      fold_rows_of<4>(srp, ea, rr);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * T + tid;
+        if (i < np) {
+          scol[i] = cc[k] | (rr[k] << 26);
+          sval[i] = vv[k];
+        }
+      }
+    }
+    __syncthreads();
+    SQLLM_PROBE(tl, 3, tid == 0);  // share staged
+    // ---- walk: T >> lr groups, contiguous runs of the pass ----
+    const int per = (np + (T >> lr) - 1) >> (__builtin_ctz(T) - lr);
+    int e = (tid >> lr) * per;  // (index within the pass)
+    int g_hi = e + per;
+    if (g_hi > np) g_hi = np;
+    if (e < g_hi) {
+      int rprev = (unsigned)scol[e] >> 26;
+      float acc = 0.f;
+      auto step = [&](unsigned cr, float v, float xv) {
+        const int r = cr >> 26;
+        if (r != rprev) {
+          if (live) atomicAdd(srow + rprev, acc);
+          acc = 0.f;
+        }
+        rprev = r;
+        acc = __builtin_fmaf(v, xv, acc);
+      };
+      // (Measured and dropped: 40 gathers per round trip, columns / rows / values re-read from the stage at their use --
+      // one round trip for a typical run at 16 rows, but the range checks and second reads cost more than the round
+      // trip saves: 149 -> 163 us per 13B layer at 16 rows, profiles/r05_walk_one_round.txt.)
+      for (; e + U <= g_hi; e += U) {  // whole batches: no range checks
+        unsigned cr[U];
+        float xv[U], v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          cr[u] = (unsigned)scol[e + u];
+          v[u] = sval[e + u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = xl[(size_t)(cr[u] & 0x3FFFFFFu) << csh];
+#pragma unroll
+        for (int u = 0; u < U; ++u) step(cr[u], v[u], xv[u]);
+      }
+      if (e < g_hi) {  // the run's last, partial batch (clamped re-reads of its last non-zero, skipped)
+        unsigned cr[U];
+        float xv[U], v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ee = e + u < g_hi ? e + u : g_hi - 1;
+          cr[u] = (unsigned)scol[ee];
+          v[u] = sval[ee];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = xl[(size_t)(cr[u] & 0x3FFFFFFu) << csh];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (e + u < g_hi) step(cr[u], v[u], xv[u]);
+      }
+      if (live) atomicAdd(srow + rprev, acc);
+    }
+    SQLLM_PROBE(tl, 4, tid == 0);  // wave 0's groups walked
+    __syncthreads();  // the stage is free again (next pass, or the caller's slabs)
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // top-X role: full_rows is fp32 [K, topX] row-major; a workgroup takes kTopxRows consecutive k's,
 // i.e. one contiguous slab of kTopxRows*topX floats, and streams it coalesced (the reference keeps
 // topX of 128 lanes busy with stride-topX reads, quant_cuda_kernel.cu:1113-1118).
 // ------------------------------------------------------------------------------------------------
-template <int T, typename XT, typename AT, bool XCOH = false, typename GATE = NoGate>
+// RB: batch rows per pass (loads of all of them in flight together, one barrier pair per pass).  The batch-1 kernels
+// use 1 (their register budget); the fused small launch 8 -- row by row, a 16-row launch kept its top-X workgroups (first
+// in the grid) for 17 us, and the dense workgroups that found no slot beside them became a second round
+// (profiles/r05_small_split_timeline.txt).
+template <int T, typename XT, typename AT, bool XCOH = false, typename GATE = NoGate, int RB = 1>
 __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
                                           const float* __restrict__ full_rows,
                                           const int* __restrict__ full_idx, int topX, int K, int N,
@@ -511,8 +762,9 @@ __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
     // reads 4 consecutive rows of the slab (contiguous), every thread keeps ONE partial sum in a
     // register, two cross-lane adds fold the wave's 4 lane rows, the 8 waves meet in LDS through
     // plain stores.  No LDS atomics (64 lanes on 10 addresses execute one lane at a time: that and
-    // two more barriers cost 0.6-0.9 us on the grouped 7B launches), one barrier per batch row.
+    // two more barriers cost 0.6-0.9 us on the grouped 7B launches), one barrier pair per pass of RB batch rows.
     static_assert(T == 512 && kTopxRows % 32 == 0, "32 lane rows x NI k's cover the slab");
+    static_assert(RB * (T / 64) * 16 <= kTopxLds && 16 * RB <= T, "a pass's partial sums: [RB][waves][16]");
     constexpr int NI = kTopxRows / 32;
     const int c = tid & 15, krow = tid >> 4;  // krow 0..31
     const int lane = tid & 63, wave = tid >> 6;
@@ -526,24 +778,39 @@ __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
     }
     const int dst = live ? full_idx[c] : 0;
     gate();  // (gated pass: the slab of full_rows is in registers, vec comes after the gate)
-    for (int b = 0; b < nb; ++b) {
-      const XT* xb = x + (size_t)(b0 + b) * K;
-      float p = 0.f;
+    for (int bp = 0; bp < nb; bp += RB) {
+      float p[RB];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int k = k0 + krow + 32 * i;
-        p = __builtin_fmaf(frv[i], k < k1 ? ld_x<XCOH>(xb + k) : 0.f, p);
+      for (int r = 0; r < RB; ++r) {
+        const int b = bp + r < nb ? bp + r : nb - 1;  // (rows past the batch: the last one again; never added)
+        const XT* xb = x + (size_t)(b0 + b) * K;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int k = k0 + krow + 32 * i;
+          q = __builtin_fmaf(frv[i], k < k1 ? ld_x<XCOH>(xb + k) : 0.f, q);
+        }
+        p[r] = q;
       }
-      p += __shfl_xor(p, 16, 64);
-      p += __shfl_xor(p, 32, 64);
-      if (b > 0) __syncthreads();  // the previous batch row's sums have been read
-      if (lane < 16) lds[wave * 16 + lane] = p;
-      __syncthreads();
-      if (tid < topX) {
-        float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < T / 64; ++w) sum += lds[w * 16 + tid];
-        acc_add(y + (size_t)(b0 + b) * N + dst, sum);
+      for (int r = 0; r < RB; ++r) {
+        p[r] += __shfl_xor(p[r], 16, 64);
+        p[r] += __shfl_xor(p[r], 32, 64);
+      }
+      if (bp > 0) __syncthreads();  // the previous pass's sums have been read
+      if (lane < 16) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) lds[(r * (T / 64) + wave) * 16 + lane] = p[r];
+      }
+      __syncthreads();
+      if (tid < 16 * RB) {
+        const int r = tid >> 4, cc = tid & 15;
+        if (cc < topX && bp + r < nb) {
+          float sum = 0.f;
+#pragma unroll
+          for (int w = 0; w < T / 64; ++w) sum += lds[(r * (T / 64) + w) * 16 + cc];
+          acc_add(y + (size_t)(b0 + bp + r) * N + full_idx[cc], sum);
+        }
       }
     }
     return;
@@ -568,6 +835,75 @@ __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
       __syncthreads();
       for (int c = tid; c < topX; c += T) acc_add(yb + full_idx[c], sacc[c]);
       __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-X role of the fused small launch when vec comes TRANSPOSED (xT[k][2^lr], sqllm_transpose_small): the slabs
+// [s0, s1) of kTopxRows k's each, all batch rows at once -- the 16 lanes of a lane row read ONE line per k for every
+// batch row (row by row from vec: 16 x 8 scalar loads per thread and slab, 4.5 us per pass of 8 rows), the partial
+// sums stay in registers across the slabs, one reduction at the end.  A workgroup therefore takes several slabs and
+// an op needs only 8-16 such workgroups: few enough to sit beside ONE round of dense workgroups for the whole launch.
+//   lds: 16 x (T / 64) x 16 floats
+// ------------------------------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ void topx_role_xt(const float* __restrict__ xT, int lr, float* __restrict__ y,
+                                             const float* __restrict__ full_rows, const int* __restrict__ full_idx, int topX,
+                                             int K, int N, int nb, int s0, int s1, float* lds) {
+  static_assert(T == 512 && kTopxRows % 32 == 0, "32 lane rows x NI k's cover a slab");
+  constexpr int NI = kTopxRows / 32;
+  const int tid = threadIdx.x;
+  const int c = tid & 15, krow = tid >> 4;
+  const int lane = tid & 63, wave = tid >> 6;
+  const bool live = c < topX;
+  const int rp = 1 << lr;
+  float p[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) p[r] = 0.f;
+  for (int s = s0; s < s1; ++s) {
+    const int k0 = s * kTopxRows;
+#pragma unroll 4
+    for (int i = 0; i < NI; ++i) {  // (four k's -- 20 loads -- in flight per thread: the role is a chain of round trips)
+      const int k = k0 + krow + 32 * i;
+      const int kc = k < K ? k : K - 1;  // clamped re-read, its weight zero
+      const float f = (live && k < K) ? full_rows[(size_t)kc * topX + c] : 0.f;
+      const float* xk = xT + ((size_t)kc << lr);
+      if (rp == 2) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(xk);
+        p[0] = __builtin_fmaf(f, v.x, p[0]);
+        p[1] = __builtin_fmaf(f, v.y, p[1]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (4 * q < rp) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xk + 4 * q);
+            p[4 * q] = __builtin_fmaf(f, v.x, p[4 * q]);
+            p[4 * q + 1] = __builtin_fmaf(f, v.y, p[4 * q + 1]);
+            p[4 * q + 2] = __builtin_fmaf(f, v.z, p[4 * q + 2]);
+            p[4 * q + 3] = __builtin_fmaf(f, v.w, p[4 * q + 3]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    p[r] += __shfl_xor(p[r], 16, 64);
+    p[r] += __shfl_xor(p[r], 32, 64);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[(r * (T / 64) + wave) * 16 + lane] = p[r];
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const int r = tid >> 4, cc = tid & 15;
+    if (cc < topX && r < nb) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < T / 64; ++w) sum += lds[(r * (T / 64) + w) * 16 + cc];
+      acc_add(y + (size_t)r * N + full_idx[cc], sum);
     }
   }
 }

@@ -70,14 +70,17 @@ class OpSequence:
     """A fixed list of ops `ys[i] += layer_i(xs[i])` with all pointers resolved up front."""
 
     def __init__(self, layers, xs, ys, batched: bool = False, fuse_shared_input: bool = False,
-                 linear: bool = False, fold_topx: bool = True):
+                 linear: bool = False, fold_topx: bool = True, workspace: bool = True):
         """fuse_shared_input: consecutive ops that read the SAME x tensor (and agree in K, bits,
         batch) are enqueued as one kernel (sqllm_launch_group), up to 4 per launch -- q/k/v and
         gate/up of a decoder layer.
         linear: `ys[i] = fp16(layer_i(xs[i]) + bias_i)` with fp16 xs / ys (ys overwritten) instead
         of the operator semantics `ys[i] += layer_i(xs[i])` on fp32.
         fold_topx (fused linears only): hand the kernel a CSR that contains the layer's top-X rows
-        (`fold_topx_into_csr`, built once per layer) instead of the separate dense rows."""
+        (`fold_topx_into_csr`, built once per layer) instead of the separate dense rows.
+        workspace (batched operator sequences): own ONE workspace buffer for the pass, sized by
+        sqllm_workspace_bytes, and launch through the `_ws` entry points -- the library then allocates
+        nothing (False: the workspace-less names)."""
         if not (len(layers) == len(xs) == len(ys)):
             raise ValueError("layers, xs, ys must have equal length")
         self.n = len(layers)
@@ -136,12 +139,25 @@ class OpSequence:
         self._sizes = (ctypes.c_int32 * max(self.n_groups, 1))(*[len(g) for g in self.groups])
         self._lib = _lib.load()
         self._done = ctypes.c_int32(0)
+        # one workspace for the whole pass (its groups run one after the other on one stream)
+        self._ws = None
+        if workspace and batched and not linear and self.n and hasattr(self._lib, "sqllm_workspace_bytes"):
+            need, at = 0, 0
+            for g in self.groups:
+                first = ctypes.cast(ctypes.byref(self.ops, at * ctypes.sizeof(_lib.SqllmOp)), ctypes.POINTER(_lib.SqllmOp))
+                need = max(need, int(self._lib.sqllm_workspace_bytes(first, len(g))))
+                at += len(g)
+            if need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
 
     def launch(self) -> None:
         """Enqueue the whole pass on the current stream of the sequence's device (one FFI crossing)."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if self.linear:
             rc = self._lib.sqllm_linear_f16_groups(self.lins, self._sizes, self.n_groups, stream, ctypes.byref(self._done))
+        elif self._ws is not None:
+            rc = self._lib.sqllm_launch_groups_ws(self.ops, self._sizes, self.n_groups, self._ws.data_ptr(), self._ws.numel(), stream,
+                                                  ctypes.byref(self._done))
         else:
             rc = self._lib.sqllm_launch_groups(self.ops, self._sizes, self.n_groups, stream, ctypes.byref(self._done))
         if rc != 0:
@@ -157,7 +173,11 @@ class OpSequence:
             raise NotImplementedError("per-launch profiling is provided for operator sequences only")
         out = (ctypes.c_float * max(self.n_groups, 1))()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self._lib.sqllm_profile_groups(self.ops, self._sizes, self.n_groups, stream, int(reps), out)
+        if self._ws is not None:
+            rc = self._lib.sqllm_profile_groups_ws(self.ops, self._sizes, self.n_groups, self._ws.data_ptr(), self._ws.numel(), stream,
+                                                   int(reps), out)
+        else:
+            rc = self._lib.sqllm_profile_groups(self.ops, self._sizes, self.n_groups, stream, int(reps), out)
         _lib.check(rc, "sqllm_profile_groups")
         out = (ctypes.c_float * self.n_groups).from_buffer(out)
         return np.ctypeslib.as_array(out).astype(np.float64).copy()
