@@ -278,6 +278,8 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
       float sum = 0.f;
 #pragma unroll
       for (int w = 0; w < WAVES; ++w) sum += slabs[w * (16 * 64) + e];
+      if (!is_finite_f32(sum) && r < batch && col < N)  // non-finite operands: the reference's fp32 chain (sqllm_split_common.h)
+        sum = dense_term_fp32<BITS>(x + (size_t)r * K, reinterpret_cast<const uint32_t*>(q), lut, N, col, u_beg * KU, u_end * KU);
       if constexpr (FOLD) {  // the CSR walk's sums; zero again for the next piece (this thread is the element's only reader)
         const int se = (e >> 6) * kFoldSumStride + (e & 63);
         sum += ssum[se];

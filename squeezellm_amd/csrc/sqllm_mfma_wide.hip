@@ -212,7 +212,8 @@ constexpr int kWideSlabFloats = 64 * kTileN;  // a wave's 64 x 64 sums
 template <int BITS, int XMODE>
 __device__ __forceinline__ void dense_role_mfma_wide(const void* __restrict__ xv, const u32x4* __restrict__ q,
                                                      float* __restrict__ y, const float* __restrict__ lut, int K, int N, int batch,
-                                                     int m0, int ct, int u_beg, int u_end, bool atomic, float* __restrict__ slab) {
+                                                     int m0, int ct, int u_beg, int u_end, bool atomic, float* __restrict__ slab,
+                                                     const float* __restrict__ x32) {
   using F = Fmt<BITS>;
   constexpr int MB = 4;
   constexpr int L = F::kLut, R = F::kRows, KU = F::kK;
@@ -377,6 +378,20 @@ __device__ __forceinline__ void dense_role_mfma_wide(const void* __restrict__ xv
   // 16-byte read-add-write; K slices add atomically -- the L2 takes ~1.2 fp32 atomics per clock and channel, 57 M of them
   // (13B gate/up, 2048 rows, two slices) were 177 us of a 1.39-ms kernel (profiles/r04_wide_ablate.txt).
   const int c0 = col0 + 4 * i16;
+  // non-finite operands (sqllm_split_common.h): a non-finite sum is recomputed as the reference's fp32 chain over this
+  // workgroup's k's, out of the fp32 vec (x32) -- cold code
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (!is_finite_f32(acc[mb][j][e])) {
+          const int r = m0 + 16 * mb + 4 * grp + e, col = c0 + j;
+          if (r < batch && col < N)
+            acc[mb][j][e] = dense_term_fp32<BITS>(x32 + (size_t)r * K, reinterpret_cast<const uint32_t*>(q), lut, N, col, u_beg * KU, u_end * KU);
+        }
+      }
   if (slab) {
     // a K slice with scratch: its 64 x 64 sums go out as a 16-KB slab in lane order (16 stores of 1 KB per wave); the
     // launch that follows (sqllm_wide_reduce) adds a tile's slabs to mul.  Adding them here atomically cost 74 of 151 us
@@ -453,7 +468,7 @@ __global__ void __launch_bounds__(256) sqllm_split_vec(const float* __restrict__
 // CU -- are cut into gm.k_slices K slices of gm.units_per_wg units, one workgroup each (make_plan_wide).
 template <int BITS, bool XP>
 __global__ void __launch_bounds__(kWaves * 64, 2)
-sqllm_fused_wide(const void* xv, const uint32_t* flags, int full_units, float* slabs, const GroupArgs ga) {
+sqllm_fused_wide(const void* xv, const uint32_t* flags, int full_units, float* slabs, const GroupArgs ga, const float* x32) {
   __shared__ __attribute__((aligned(16))) char lds[kWideTiles * split_codebook_bytes(BITS)];
   static_assert(kWaves == kWideTiles, "one column tile per wave");
   const Segment sg = ga.seg[0];
@@ -484,10 +499,10 @@ sqllm_fused_wide(const void* xv, const uint32_t* flags, int full_units, float* s
     static_assert(kSplitFlagWgs == 256, "four flags per lane");
     const uint32_t f = flags[lane] | flags[lane + 64] | flags[lane + 128] | flags[lane + 192];
     const bool has_lo = __builtin_amdgcn_ballot_w64(f != 0) != 0;
-    if (has_lo) dense_role_mfma_wide<BITS, 3>(xv, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced, slab);
-    else dense_role_mfma_wide<BITS, 2>(xv, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced, slab);
+    if (has_lo) dense_role_mfma_wide<BITS, 3>(xv, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced, slab, x32);
+    else dense_role_mfma_wide<BITS, 2>(xv, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced, slab, x32);
   } else {
-    dense_role_mfma_wide<BITS, 0>(xv, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced, slab);
+    dense_role_mfma_wide<BITS, 0>(xv, q, sg.y, sg.lut, gm.K, gm.N, gm.batch, m0, ct, u_beg, u_end, sliced, slab, x32);
   }
 }
 
@@ -532,13 +547,13 @@ hipError_t launch_wide_bits(const LaunchArgs& a, hipStream_t stream) {
   hipEvent_t stop = slabs ? nullptr : a.ev_stop;  // (with slabs the op ends with the reduce launch)
   if (a.planes) {
     auto kern = sqllm_fused_wide<BITS, true>;
-    if (a.ev_start || stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, stop, 0, a.planes, a.plane_flags, a.wide_full_units, slabs, a.ga);
-    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.planes, a.plane_flags, a.wide_full_units, slabs, a.ga);
+    if (a.ev_start || stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, stop, 0, a.planes, a.plane_flags, a.wide_full_units, slabs, a.ga, static_cast<const float*>(a.x));
+    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.planes, a.plane_flags, a.wide_full_units, slabs, a.ga, static_cast<const float*>(a.x));
   } else {
     auto kern = sqllm_fused_wide<BITS, false>;
     const uint32_t* none = nullptr;
-    if (a.ev_start || stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, stop, 0, a.x, none, a.wide_full_units, slabs, a.ga);
-    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.x, none, a.wide_full_units, slabs, a.ga);
+    if (a.ev_start || stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, stop, 0, a.x, none, a.wide_full_units, slabs, a.ga, static_cast<const float*>(a.x));
+    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.x, none, a.wide_full_units, slabs, a.ga, static_cast<const float*>(a.x));
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || !slabs) return e;

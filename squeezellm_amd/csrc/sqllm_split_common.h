@@ -156,6 +156,40 @@ __device__ __forceinline__ void split_phase(const u32x4 (&t)[Fmt<BITS>::kRows], 
   }
 }
 
+// ---- non-finite operands ----
+// The split is exact for finite values only: an infinite vec value or codebook entry gives inf - inf = NaN in its mid part,
+// and every sum it takes part in comes out NaN, where the reference's fp32 FMA chain (squeezellm/quant_cuda_kernel.cu:
+// 1011-1036) gives +-inf (or NaN only for inf - inf and 0 x inf).  A finite result therefore proves finite operands
+// (and an overflowing sum is non-finite in both); a NON-FINITE sum of the matrix instructions is recomputed here the
+// reference's way -- one fp32 FMA chain over the workgroup's k's, index by index out of qweight -- before it is added to
+// mul.  Cold code: it runs for outputs that NaN / inf operands reach, at ~10 instructions per weight.
+__device__ __forceinline__ bool is_finite_f32(float v) { return (__builtin_bit_cast(uint32_t, v) & 0x7F800000u) != 0x7F800000u; }
+
+// index of weight (k, col) in the packed matrix (squeezellm/quant.py:180-203: 4-bit -- nibble k % 8 of row k / 8;
+// 3-bit -- field k % 32 of the 96-bit little-endian stream in rows 3 (k / 32) .. + 2)
+template <int BITS>
+__device__ __forceinline__ uint32_t packed_index(const uint32_t* __restrict__ q, int N, int k, int col) {
+  if constexpr (BITS == 4) {
+    return (q[(size_t)(k >> 3) * N + col] >> (4 * (k & 7))) & 15u;
+  } else {
+    const int bit = 3 * (k & 31), w = bit >> 5, o = bit & 31;
+    const size_t base = (size_t)(3 * (k >> 5) + w) * N + col;
+    uint32_t f = q[base] >> o;
+    if (o > 29) f |= q[base + N] << (32 - o);
+    return f & 7u;
+  }
+}
+
+// sum over k in [k_beg, k_end) of lookup_table[col][index(k, col)] * vec[row][k] as ONE fp32 FMA chain
+template <int BITS>
+__device__ __forceinline__ float dense_term_fp32(const float* __restrict__ x_row, const uint32_t* __restrict__ q,
+                                                 const float* __restrict__ lut, int N, int col, int k_beg, int k_end) {
+  const float* lc = lut + (size_t)col * (1 << BITS);
+  float s = 0.f;
+  for (int k = k_beg; k < k_end; ++k) s = __builtin_fmaf(lc[packed_index<BITS>(q, N, k, col)], x_row[k], s);
+  return s;
+}
+
 // exact split of one codebook value into its LDS entry {hi | mid << 16, lo}
 __device__ __forceinline__ u32x2 split_entry(float v) {
   const uint32_t b = __builtin_bit_cast(uint32_t, v);

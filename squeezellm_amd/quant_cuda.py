@@ -81,13 +81,67 @@ def _persist(t, dtype, name: str):
     """(data_ptr, device index, shape) of a layer's persistent operand, validated on first sight.  The entry is
     dropped when the tensor dies (weakref callback) and re-validated if its storage moved."""
     e = _persistent.get(id(t))
-    if e is not None and e[0]() is t and e[1] == t.data_ptr():
+    # a hit needs the same object, storage, ROLE (the dtype this operand must have) and shape: a tensor validated as int32
+    # `cols` and later passed as `vals`, or resized in place (same data_ptr), is validated again
+    if e is not None and e[0]() is t and e[1] == t.data_ptr() and e[4] is dtype and t.shape == e[3]:
         return e
     ptr = _dev_ptr(t, dtype, name)
     key = id(t)
-    e = (weakref.ref(t, lambda _r, k=key: _persistent.pop(k, None)), ptr, t.get_device(), tuple(t.shape))
+    e = (weakref.ref(t, lambda _r, k=key: _persistent.pop(k, None)), ptr, t.get_device(), tuple(t.shape), dtype)
     _persistent[key] = e
     return e
+
+
+# ---- caller workspace of the batched operators (include/sqllm_hip.h: sqllm_launch_ws) ----
+# The reference's launchers allocate nothing (quant_cuda_kernel.cu:580-657); here a batched op with sparse terms reads a
+# transposed copy of vec (and, wider, bf16 planes / slabs) out of a workspace.  This module owns ONE buffer per (device,
+# stream), grown on demand, and launches through sqllm_launch_ws: the library then allocates nothing and never touches
+# the default memory pool.  (A buffer is replaced, not freed early: torch's caching allocator keeps a block that was
+# allocated on a stream alive for the work already enqueued there.)
+_workspaces = {}
+_ws_need = {}
+_op = None
+
+
+def _workspace(dev: int, stream: int, need: int):
+    ws = _workspaces.get((dev, stream))
+    if ws is None or ws.numel() < need:
+        ws = _workspaces[(dev, stream)] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=torch.device("cuda", dev))
+    return ws
+
+
+def _launch_ws(dev: int, bits, batch, K, width, pv, pq, pm, pl, csr=None, topx=None):
+    """A batched op through sqllm_launch_ws with this module's workspace of (device, current stream)."""
+    global _op
+    import ctypes
+
+    lib = _lib.load()
+    if _op is None:
+        _op = _lib.SqllmOp()
+    o = _op
+    o.bits, o.batch, o.K, o.N = bits, batch, K, width
+    o.vec, o.qweight, o.mul, o.lookup_table = pv, pq, pm, pl
+    o.rows, o.cols, o.vals, o.nnz = csr if csr is not None else (None, None, None, 0)
+    o.full_rows, o.full_row_indices, o.topX = topx if topx is not None else (None, None, 0)
+    prev = _get_device()
+    if prev != dev:
+        _set_device(dev)
+    try:
+        key = (dev, bits, batch, K, width, csr is not None and csr[3] > 0, topx is not None and topx[2] > 0)
+        need = _ws_need.get(key)
+        if need is None:
+            need = _ws_need[key] = int(lib.sqllm_workspace_bytes(ctypes.byref(o), 1))
+        stream = _raw_stream(dev)
+        if need:
+            ws = _workspace(dev, stream, need)
+            rc = lib.sqllm_launch_ws(ctypes.byref(o), ws.data_ptr(), ws.numel(), stream)
+        else:
+            rc = lib.sqllm_launch_ws(ctypes.byref(o), None, 0, stream)
+    finally:
+        if prev != dev:
+            _set_device(prev)
+    if rc:
+        _lib.check(rc, "sqllm_launch_ws")
 
 
 def _io_type(vec, mul) -> None:
@@ -192,6 +246,8 @@ def _dense(bits, batched, vec, mat, mul, lookup_table):
     pq, dev, height, width, K = _qweight(mat, bits, "mat")
     pl = _lut(lookup_table, width, bits, dev)
     pv, pm, batch = _vec_mul(vec, mul, K, width, batched, dev)
+    if batched and batch >= 64:  # (the wide form's planes / slabs; narrower dense ops need no workspace)
+        return _launch_ws(dev, bits, batch, K, width, pv, pq, pm, pl)
     fn = _fn(f"sqllm_vecquant{bits}matmul_nuq_perchannel{_SFX[batched]}")
     _launch(fn, dev, (pv, pq, pm, pl, height, width, batch, K) if batched else (pv, pq, pm, pl, height, width))
 
@@ -202,6 +258,8 @@ def _spmv(bits, batched, rows, cols, mat, vec, mul, num_rows, matq, lookup_table
     pl = _lut(lookup_table, width, bits, dev)
     pr, pc, pvl, nnz = _csr(rows, cols, mat, num_rows, width, dev)
     pv, pm, batch = _vec_mul(vec, mul, K, width, batched, dev)
+    if batched and batch >= 2:  # (what a batch needs beside its operands comes out of this module's workspace)
+        return _launch_ws(dev, bits, batch, K, width, pv, pq, pm, pl, csr=(pr, pc, pvl, nnz))
     fn = _fn(f"sqllm_vecquant{bits}matmul_spmv_nuq_perchannel{_SFX[batched]}")
     head = (pr, pc, pvl, pv, pm, int(num_rows), pq, pl, height, width, nnz)
     _launch(fn, dev, head + (batch, K) if batched else head)
@@ -224,6 +282,8 @@ def _hybrid(bits, batched, rows, cols, mat, vec, full_rows, full_row_indices, mu
     if efr[2] != dev or efi[2] != dev:
         raise RuntimeError(f"all operands must be on cuda:{dev}, found full_rows / full_row_indices elsewhere")
     pv, pm, batch = _vec_mul(vec, mul, K, width, batched, dev)
+    if batched and batch >= 2:
+        return _launch_ws(dev, bits, batch, K, width, pv, pq, pm, pl, csr=(pr, pc, pvl, nnz), topx=(efr[1], efi[1], topX))
     fn = _fn(f"sqllm_vecquant{bits}matmul_spmv_hybrid_nuq_perchannel{_SFX[batched]}")
     head = (pr, pc, pvl, pv, efr[1], efi[1], pm, int(num_rows), pq, pl, height, width, nnz, topX)
     _launch(fn, dev, head + (batch, K) if batched else head)
