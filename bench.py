@@ -149,6 +149,7 @@ def roofline_leg(seq, layers, bytes_per_op, cfg, config_name, fused):
     n_launch = seq.n_groups
     achieved = pass_bytes / n_launch / (avg_us * 1e-6) / 1e9
     traffic, source = pmc_traffic_per_launch(config_name, fused)
+    kt_us, kt_source = rocprof_kernel_us_per_launch(config_name, fused)
     roof = {
         "bound": "hbm",
         "achieved": round(achieved, 1),
@@ -160,6 +161,11 @@ def roofline_leg(seq, layers, bytes_per_op, cfg, config_name, fused):
         # command (tools/collect_profiles.sh), gfx950 correction applied (FETCH_SIZE x 2); null if none
         "traffic": traffic,
         "traffic_source": source,
+        # the same fraction from the COMMITTED rocprofv3 --kernel-trace --stats summary of this command (profiled clocks,
+        # the box of that session: it need not be this one): algorithmic bytes per launch / its mean kernel duration
+        "frac_rocprof": None if kt_us is None else round(pass_bytes / n_launch / (kt_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+        "avg_kernel_us_rocprof": None if kt_us is None else round(kt_us, 3),
+        "frac_rocprof_source": kt_source,
         "kernel": f"sqllm_fused_matvec<{cfg['bits']},1>",
         "avg_kernel_us": round(avg_us, 3),
         "launches_per_step": n_launch,
@@ -167,6 +173,32 @@ def roofline_leg(seq, layers, bytes_per_op, cfg, config_name, fused):
         "sum_kernel_ms_per_step": round(float(us.sum()) * 1e-3, 4),
     }
     return roof, per_shape_table(seq, layers, bytes_per_op, us)
+
+
+def rocprof_kernel_us_per_launch(config_name: str, fused: bool):
+    """Mean duration of a launch of this config's pass in the newest committed kernel-trace summary
+    (profiles/<round>_kt_<w4|w3|w4s45>.summary.txt, tools/collect_profiles.sh: total_us / calls over the sqllm kernels)."""
+    names = {"7b-w4-s0": "kt_w4.summary.txt", "7b-w3-s45": "kt_w3.summary.txt", "7b-w4-s45": "kt_w4s45.summary.txt"}
+    if config_name not in names or not fused:
+        return None, None
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{names[config_name]}")
+        try:
+            lines = open(path).read().splitlines()
+        except OSError:
+            continue
+        calls, total = 0, 0.0
+        for ln in lines:
+            f = ln.split()
+            if len(f) >= 8 and f[0].startswith("sqllm::sqllm_fused_matvec"):
+                try:
+                    c, t = int(f[-6]), float(f[-5])
+                except ValueError:
+                    continue
+                calls, total = calls + c, total + t
+        if calls:
+            return total / calls, f"committed kernel trace profiles/{rnd}_{names[config_name]} ({calls} dispatches; not a live measurement)"
+    return None, None
 
 
 def pmc_traffic_per_launch(config_name: str, fused: bool):
@@ -193,7 +225,7 @@ def pmc_traffic_per_launch(config_name: str, fused: bool):
         n = sum(int(a) for a, _ in rows)
         return sum(int(a) * float(b.replace(",", "")) for a, b in rows) / n
 
-    for rnd in ("r04", "r03", "r02", "r01"):  # newest committed round first
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):  # newest committed round first
         fetch = mean_kib(f"{rnd}_{names[config_name][0]}", "FETCH_SIZE")
         if fetch is None:
             continue
@@ -681,7 +713,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    # SQLLM_BENCH_FORCE_DIST=1 with ONE rank and --gpus N > 1: a dry run of the N-GPU command's code path on one GPU (the
+    # routing --gpus N takes -- 65B: layer-sharded ring pipeline -- under a real one-rank RCCL group), so that the driver's
+    # first N-GPU run is not also the first run of that path; the line says so and reports n_gpus = 1
+    dry_world = args.gpus if (os.environ.get("SQLLM_BENCH_FORCE_DIST") == "1" and world == 1 and args.gpus > 1) else 0
+    if world != args.gpus and not dry_world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -700,8 +736,8 @@ def main():
     hidden = spec["linears"][0][1]
     mode = args.parallel
     if mode == "auto":
-        mode = "pipeline" if (world > 1 and args.config.startswith("65b")) else "replicas"
-    if world == 1 and args.parallel not in ("pipeline", "columns"):
+        mode = "pipeline" if ((world > 1 or dry_world) and args.config.startswith("65b")) else "replicas"
+    if world == 1 and not dry_world and args.parallel not in ("pipeline", "columns"):
         mode = "replicas"  # (an explicit --parallel pipeline / columns on one GPU runs the degenerate one-rank form)
 
     def sync():
@@ -794,12 +830,13 @@ def main():
             if mode == "replicas" else ("column-sharded linears, one all-gather of the mul slices per launch group" if mode == "columns"
                                         else "sequence + ring all-gather"),
             "launches_per_token": seq.n_groups if mode == "replicas" else None,
-            "parallelism": "single GPU" if world == 1 else (
-                f"dp{world}: independent token streams, one full model replica per GPU, no data-path collective"
+            "parallelism": "single GPU" if (world == 1 and not dry_world) else ((
+                f"dp{dry_world or world}: independent token streams, one full model replica per GPU, no data-path collective"
                 if mode == "replicas" else
-                (f"tp{world} by output column: every GPU holds 1/{world} of every linear, RCCL all-gather of the mul slices per launch group"
+                (f"tp{dry_world or world} by output column: every GPU holds 1/{dry_world or world} of every linear, RCCL all-gather of the mul slices per launch group"
                  if mode == "columns" else
-                 f"pp{world}: layer-sharded ring pipeline, RCCL all-gather of the hidden state per tick")),
+                 f"pp{dry_world or world}: layer-sharded ring pipeline, RCCL all-gather of the hidden state per tick"))
+                + (" -- DRY RUN of that path on ONE rank (SQLLM_BENCH_FORCE_DIST=1)" if dry_world else "")),
             "world_size": world,
             "rccl_ranks": dist.get_world_size() if use_dist else 0,  # 0: no process group (single process)
             "ops_per_token": model_layers * per_layer,

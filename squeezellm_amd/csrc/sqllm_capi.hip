@@ -428,7 +428,6 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "mfma_fuse_small")) { knobs().mfma_fuse_small.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "mfma_fuse_sparse")) { knobs().mfma_fuse_sparse.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "scratch_pool_threshold")) { knobs().scratch_pool_threshold.store(value ? 1 : 0); return SQLLM_OK; }
-  if (!strcmp(name, "csr_fold")) { knobs().csr_fold.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "small_wgs_per_cu")) { knobs().small_wgs_per_cu.store(value); return SQLLM_OK; }
   if (!strcmp(name, "small_reserve_topx")) { knobs().small_reserve_topx.store(value ? 1 : 0); return SQLLM_OK; }
   if (g_experimental.set_option) return g_experimental.set_option(name, value);  // (measurement library)
@@ -454,7 +453,6 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "mfma_fuse_small")) { *value = knobs().mfma_fuse_small.load(); return SQLLM_OK; }
   if (!strcmp(name, "mfma_fuse_sparse")) { *value = knobs().mfma_fuse_sparse.load(); return SQLLM_OK; }
   if (!strcmp(name, "scratch_pool_threshold")) { *value = knobs().scratch_pool_threshold.load(); return SQLLM_OK; }
-  if (!strcmp(name, "csr_fold")) { *value = knobs().csr_fold.load(); return SQLLM_OK; }
   if (!strcmp(name, "small_wgs_per_cu")) { *value = knobs().small_wgs_per_cu.load(); return SQLLM_OK; }
   if (!strcmp(name, "small_reserve_topx")) { *value = knobs().small_reserve_topx.load(); return SQLLM_OK; }
   if (g_experimental.get_option) return g_experimental.get_option(name, value);  // (measurement library)
@@ -482,10 +480,7 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
     }
   }
   else if (takes_cols_path(op)) make_plan_cols(op, &gm);
-  else {
-    make_plan(op, &gm);
-    if (gm.batch >= 2 && gm.nnz > 0 && knobs().csr_fold.load(std::memory_order_relaxed)) fold_csr_into_dense(&gm);  // (as launch_group_with_events)
-  }
+  else make_plan(op, &gm);
   const bool small_split = mfma && !wide && takes_small_split(op);
   if (small_split) {  // the fused small launch: CSR term folded into the dense workgroups, top-X slabs in the grid
     // (as launched with a workspace: vec transposed, 8-16 top-X workgroups, the dense ranges planned beside them)
@@ -851,8 +846,6 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     // fused linear: a column's K slices + the CSR chunks its row can be spread over must fit the 6-bit count
     const int csr_bound = (op->rows && op->nnz > 0) ? op->K / sqllm::kCsrChunk + 2 : 0;
     make_plan(op, &sg.gm, n, lin ? (sqllm::kMaxContrib - csr_bound > 1 ? sqllm::kMaxContrib - csr_bound : 1) : sqllm::kMaxSlices);
-    // batch tiles of 2..8 rows: the CSR term is walked by the dense workgroups themselves (sqllm_fused.h: FOLDABLE)
-    if (!lin && sg.gm.batch >= 2 && sg.gm.nnz > 0 && knobs().csr_fold.load(std::memory_order_relaxed)) fold_csr_into_dense(&sg.gm);
     if (lin) {
       // accumulate into the workspace plane; op->mul is the fp16 result
       sg.y = reinterpret_cast<float*>(lin[i].workspace);

@@ -66,11 +66,8 @@ namespace sqllm {
 template <int BT, int WAVES, int ABL>
 __device__ __forceinline__ void dense_epilogue(const f32x2 (&acc)[2][BT], float* slabs, const float* topx_sum,
                                                bool fold_topx, float* __restrict__ y, int N, int col0, int b0,
-                                               int nb, int lane, int wave, const Segment& sg, const Segment* lin
-#ifdef SQLLM_ABLATION_BUILD
-                                               , unsigned long long* tl
-#endif
-) {
+                                               int nb, int lane, int wave, const Segment& sg, const Segment* lin,
+                                               unsigned long long* tl /* timeline stamps: sqllm_probe.h (null in the product) */) {
   const int i16 = lane & 15, grp = lane >> 4;
   if constexpr (ABL & 8) {
     if (acc[0][0].x + acc[0][0].y + acc[1][0].x + acc[1][0].y == 12345.678f) y[0] = 1.f;  // keep the work alive
@@ -147,9 +144,7 @@ __device__ __forceinline__ void dense_epilogue(const f32x2 (&acc)[2][BT], float*
         }
       }
     }
-#ifdef SQLLM_ABLATION_BUILD
-    if (tl && lane == 0) tl[3] = __builtin_amdgcn_s_memrealtime();  // atomics issued by the combining wave
-#endif
+    SQLLM_PROBE(tl, 3, lane == 0);  // atomics issued by the combining wave
     if (lin) {  // all the round trips are in flight before the first result is looked at
 #pragma unroll
       for (int b = 0; b < BT; ++b) {
@@ -312,18 +307,6 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
       for (int i = 0; i < RPW; ++i) ev[i] = src[2 * (st_h * RPW + i) + (lane >> 5)];
     }
   }
-  // Batch tiles of an operator launch whose plan folds the CSR term into the dense workgroups (gm.fold_csr, 2-8 rows;
-  // csr_tile_fold, sqllm_roles.h): the tile's 65 row pointers are staged with the codebooks -- an UNCONDITIONAL load
-  // (see below), thread t fetches pointer t % 128 (without the term: the codebook pointer).
-  constexpr bool FOLDABLE = BT > 1 && std::is_same<XT, float>::value;
-  bool fold_csr = false;
-  int rpv = 0;
-  if constexpr (FOLDABLE) {
-    fold_csr = sg.gm.fold_csr != 0;
-    int rc = col0 + (tid & (kFoldRp - 1));
-    if (rc > N) rc = N;
-    rpv = (fold_csr ? sg.rows : reinterpret_cast<const int*>(lut))[fold_csr ? rc : 0];
-  }
   // Fused linear: the top-X rows are folded into the dense tiles.  The first 64 column indices go
   // out first (consumed right after the staging barrier, while the weight loads behind them are
   // still in flight).  The load is UNCONDITIONAL -- without top-X rows it reads the codebook
@@ -331,14 +314,10 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   // outstanding load at the join (measured: vmcnt(0) instead of vmcnt(6) before the codebook
   // staging, +0.3-0.6 us on every launch).  Operator launches keep the separate top-X role:
   // folding measured 6 % slower there (the matched workgroups become the tail of the launch).
-#ifdef SQLLM_ABLATION_BUILD
-  // timeline probe (measurement build): sg.bias, unused by operator launches, carries a buffer of
-  // 8 x u64 per workgroup; wave 0 stamps entry / barrier passed / decode done, the combining wave
-  // stamps the end.  s_memrealtime = 100 MHz constant clock, comparable across CUs.
-  unsigned long long* tl = (!lin && sg.bias) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(sg.bias)) +
-                                                   8ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y) : nullptr;
-  if (tl && tid == 0) tl[0] = __builtin_amdgcn_s_memrealtime();
-#endif
+  // timeline probe (sqllm_probe.h; nothing in the product): wave 0 stamps entry / barrier passed / decode done, the
+  // combining wave stamps the end
+  unsigned long long* tl = lin ? nullptr : SQLLM_PROBE_PTR(sg);
+  SQLLM_PROBE(tl, 0, tid == 0);
   // Branches first: between the loads below and the codebook staging there must be NO control
   // flow, or the staging waits for every outstanding load (vmcnt(0)) instead of its own.
   constexpr int kCodebookFloats = PAIR ? 4 * 64 * 128 / 4 : 4 * SUBB / 4;  // the four column sub-tables
@@ -379,9 +358,6 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
     }
   }
 
-  int* srp = reinterpret_cast<int*>(topx_sum + BT * kTileN);  // FOLDABLE: the tile's row pointers
-  if constexpr (FOLDABLE) srp[tid & (kFoldRp - 1)] = rpv;
-
   f32x2 acc[2][BT];  // [column pair][batch row]: columns 2p and 2p+1 of the lane's four
 #pragma unroll
   for (int jp = 0; jp < 2; ++jp)
@@ -396,9 +372,7 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   f32x2 accp[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};  // PAIR: (even k, odd k) per column
 
   __syncthreads();  // codebooks visible
-#ifdef SQLLM_ABLATION_BUILD
-  if (tl && tid == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
-#endif
+  SQLLM_PROBE(tl, 1, tid == 0);
 
   // u = this wave's (uniform) unit for the chunk's first step: guards are scalar branches; only the
   // per-row validity of a slice's ragged end is per lane (it zeroes x, no divergence)
@@ -465,24 +439,13 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
     decode_chunk(u0, w, xs);
   }
 
-#ifdef SQLLM_ABLATION_BUILD
-  if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
-  if (tl && lane == 0) tl[4 + (wave & 3)] = __builtin_amdgcn_s_memrealtime();  // decode end of waves 0-3
-#endif
-  if constexpr (FOLDABLE) {
-    // the CSR rows of this tile, this slice's share: sums into topx_sum ([BT][64], zeroed above), which the combining
-    // wave adds to the column sums (every wave's LDS adds precede its ticket)
-    if (fold_csr) csr_tile_fold<WAVES * 64>(x, sg.cols, sg.vals, K, b0, nb, u_beg, u_end, units_total, srp, topx_sum, tid);
-  }
+  SQLLM_PROBE(tl, 2, tid == 0);
+  SQLLM_PROBE(tl, 4 + (wave & 3), lane == 0);  // decode end of waves 0-3
   if constexpr (PAIR) {
     acc[0][0] = f32x2{accp[0].x + accp[0].y, accp[1].x + accp[1].y};
     acc[1][0] = f32x2{accp[2].x + accp[2].y, accp[3].x + accp[3].y};
   }
-  dense_epilogue<BT, WAVES, ABL>(acc, lds + kCodebookFloats, topx_sum, fold_topx || fold_csr, y, N, col0, b0, nb, lane, wave, sg, lin
-#ifdef SQLLM_ABLATION_BUILD
-                                 , tl
-#endif
-  );
+  dense_epilogue<BT, WAVES, ABL>(acc, lds + kCodebookFloats, topx_sum, fold_topx, y, N, col0, b0, nb, lane, wave, sg, lin, tl);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -545,14 +508,7 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
                                          d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds, sg, LIN ? &sg : nullptr);
   } else if (sp >= 0 && sp < gm.csr_blocks) {
     csr_role<T, BT, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds,
-                        LIN ? &sg : nullptr, gm.sparse_last >> 1, nullptr, 0,
-#ifdef SQLLM_ABLATION_BUILD
-                        (!LIN && sg.bias) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(sg.bias)) +
-                                                8ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y) : nullptr
-#else
-                        nullptr
-#endif
-    );
+                        LIN ? &sg : nullptr, gm.sparse_last >> 1, nullptr, 0, LIN ? nullptr : SQLLM_PROBE_PTR(sg));
   } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
     // (never taken when the plan folds the top-X rows into the dense tiles)
     topx_role<T, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, b0, nb, sp - gm.csr_blocks, lds);

@@ -36,7 +36,6 @@ struct Knobs {
   std::atomic<int> split_planes_min_batch{0};  // rows from which vec is split ONCE into bf16 planes in scratch (0 = the measured default; a huge value: never)
   std::atomic<int> mfma_fuse_sparse{1};  // 17 rows up to the wide form: the op's CSR / top-X workgroups in the dense launch's grid (0: a launch of their own first)
   std::atomic<int> mfma_fuse_small{1};  // ... and up to 16 rows: the group's ops with their sparse terms as ONE launch of that kernel
-  std::atomic<int> csr_fold{0};  // 1: 2..8 rows on the batch tiles: the CSR term walked by the dense workgroups (csr_tile_fold), no chunk workgroups (measured slower than the chunk role: off)
   std::atomic<int> small_reserve_topx{0};  // fused small launch: 1 = plan the dense ranges for the slots the top-X slabs leave (measured: the coarser ranges cost more than the late starters, profiles/r05_small_split_reserve.txt)
   std::atomic<int> small_wgs_per_cu{0};  // fused small launch of the split kernel: dense workgroups per CU its planner aims at (0 = default)
 };

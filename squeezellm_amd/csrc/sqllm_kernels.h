@@ -44,12 +44,11 @@ constexpr int kMaxContrib = 63;    // fused linear: contributions one column may
 //          sums BT * 64 (the slabs must not overlap the codebooks: the combine is barrier-free)
 //   csr  : kCsrSpanMax ints + kCsrSpanMax floats
 //   topx : kTopxLds
-// (batch tiles > 1 also hold the 128 staged row pointers of a folded CSR term behind the top-X sums)
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int lds_floats(int lut_entries, int waves, int bt, bool pair3 = false) {
   // pair3: the 3-bit batch-1 kernels stage 64-entry PAIR tables, 4 x 64 x 128 B per tile
-  return cmax((pair3 ? 4 * 64 * 32 : 4 * lut_entries * 32) + waves * bt * kTileN + 4 + bt * kTileN + (bt > 1 ? 128 : 0),
-              cmax(2 * kCsrSpanMax, kTopxLds));  // (+ 128: the row pointers of a folded CSR term, kFoldRp)
+  return cmax((pair3 ? 4 * 64 * 32 : 4 * lut_entries * 32) + waves * bt * kTileN + 4 + bt * kTileN,
+              cmax(2 * kCsrSpanMax, kTopxLds));
 }
 
 // Launch geometry, computed on the host (sqllm_capi.hip: make_plan) and passed by value.
@@ -65,7 +64,7 @@ struct KernelGeom {
   int topx_blocks;      // ceil(K / kTopxRows), 0 without a top-X term
   int nnz, topX;
   int sparse_last;      // 1: CSR / top-X workgroups come after the dense ones in the grid
-  int fold_csr;         // 1: the CSR term is walked by the dense workgroups themselves (csr_tile_fold; csr_blocks = 0)
+  int fold_csr;         // 1: the CSR term is walked by the dense workgroups themselves (fused small launch: csr_tile_fold_staged; csr_blocks = 0)
 };
 
 constexpr int kMaxSegments = 4;   // ops one launch can cover (they share vec, K, bits, batch)

@@ -373,12 +373,7 @@ sqllm_sparse_batched(const float* x, const GroupArgs ga, const float* xT, int Bp
   if (rows_here > pass_rows) rows_here = pass_rows;
   if (sp < gm.csr_blocks) {
     if (xT) {
-      csr_role<T, 1, float, float, true>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, m0, rows_here, sp, lds, nullptr, 0, xT, Bp
-#ifdef SQLLM_ABLATION_BUILD
-                                         , sg.bias ? reinterpret_cast<unsigned long long*>(const_cast<float*>(sg.bias)) +
-                                                         8ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y) : nullptr
-#endif
-      );
+      csr_role<T, 1, float, float, true>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, m0, rows_here, sp, lds, nullptr, 0, xT, Bp, SQLLM_PROBE_PTR(sg));
     } else {
       constexpr int CBT = 32;  // every group of rows costs the chunk a zero / gather / flush round with its barriers
       for (int bb = 0; bb < rows_here; bb += CBT) {

@@ -15,6 +15,13 @@
   do {                                                           \
     if ((tl) && (COND)) (tl)[I] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
+// a stamp stored NEGATED (the CSR chunk workgroups' entry: tells them from the dense ones)
+#define SQLLM_PROBE_NEG(tl, I, COND)                                     \
+  do {                                                                   \
+    if ((tl) && (COND)) (tl)[I] = 0ull - __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+// ablation bits of a role (measurement library: option ablate_csr): 0 in the product, where whatever they guard folds away
+#define SQLLM_ABLATION_BITS(x) (x)
 // the entry stamp with the workgroup's place in its top 16 bits: XCC id (4 bits) above HW_ID[15:8] (CU, SH, SE)
 #define SQLLM_PROBE_ENTRY(tl, COND)                                                                                          \
   do {                                                                                                                        \
@@ -32,4 +39,8 @@
 #define SQLLM_PROBE_ENTRY(tl, COND) \
   do {                              \
   } while (0)
+#define SQLLM_PROBE_NEG(tl, I, COND) \
+  do {                               \
+  } while (0)
+#define SQLLM_ABLATION_BITS(x) 0
 #endif

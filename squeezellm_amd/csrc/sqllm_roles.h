@@ -84,16 +84,14 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
   int e1 = e0 + kCsrChunk;
   if (e1 > nnz) e1 = nnz;
   if (e0 >= e1) return;
-#ifdef SQLLM_ABLATION_BUILD
-  const int cabl = lin_or_abl_bits;  // 1 = skip the role, 2 = skip the flush, 4 = skip the accumulation, 8 = no x gathers
+  // measurement library only (sqllm_probe.h: the bits are the constant 0 in the product and all of this folds away):
+  // 1 = skip the role, 2 = skip the flush, 4 = skip the accumulation, 8 = no x gathers, bits 4.. = hold the role back
+  const int cabl = SQLLM_ABLATION_BITS(lin_or_abl_bits);
   if (cabl & 1) return;
-  for (int d = cabl >> 4; d > 0; --d) __builtin_amdgcn_s_sleep(8);  // measurement: hold the role back by (cabl >> 4) x ~0.2 us
+  for (int d = cabl >> 4; d > 0; --d) __builtin_amdgcn_s_sleep(8);  // (by (cabl >> 4) x ~0.2 us)
   // timeline probe (tools/timeline.py): the entry stamp is stored NEGATED, which tells a chunk workgroup from a dense one
-  if (tl && tid == 0) tl[0] = 0ull - __builtin_amdgcn_s_memrealtime();
-#define SQLLM_CSR_STAMP(I) if (tl && tid == 0) tl[I] = __builtin_amdgcn_s_memrealtime();
-#else
-#define SQLLM_CSR_STAMP(I)
-#endif
+  SQLLM_PROBE_NEG(tl, 0, tid == 0);
+#define SQLLM_CSR_STAMP(I) SQLLM_PROBE(tl, I, tid == 0);
 
   // ---- round 1 ----
   constexpr int EPT = kCsrChunk / T;  // non-zeros per thread
@@ -399,15 +397,9 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
       for (int bb = 0; bb < BT; ++bb) {
         const int bi = bs + (bb < gb ? bb : gb - 1);
         xv[i][bb] = (bs == 0 && bb == 0) ? xg[i] : ld_x<XCOH>(x + (size_t)(b0 + bi) * K + col[i]);
-#ifdef SQLLM_ABLATION_BUILD
-        if (cabl & 8) xv[i][bb] = 1.f + bb;  // measurement: no gathers
-#endif
+        if (cabl & 8) xv[i][bb] = 1.f + bb;  // (measurement: no gathers)
       }
-#ifdef SQLLM_ABLATION_BUILD
     const bool skip_acc = cabl & 4;
-#else
-    constexpr bool skip_acc = false;
-#endif
     if (!skip_acc) {
 #pragma unroll
       for (int bb = 0; bb < BT; ++bb) {
@@ -447,9 +439,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
     if (in_lds) {
       __syncthreads();
       SQLLM_CSR_STAMP(4)  // x gathered, products scanned, row sums in LDS
-#ifdef SQLLM_ABLATION_BUILD
       if (cabl & 2) continue;
-#endif
       for (int idx = tid; idx < nm1 * gb && n > 1; idx += T) {
         const int bb = idx / nm1;
         const int i = idx - bb * nm1;
@@ -489,23 +479,33 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
 }
 
 // ------------------------------------------------------------------------------------------------
-// CSR rows FOLDED into the dense workgroups (small batches, 2..16 rows; replaces SPMV_ATOMIC_BATCHED,
-// squeezellm/quant_cuda_kernel.cu:1061-1089, for those).  CSR rows are output channels, so the non-zeros of
-// a 64-column dense tile are ONE contiguous range of cols / vals, rows[col0] .. rows[col0 + 64); the
-// workgroups that share the tile (its K slices) cut that range in proportion to their units of K, and each
-// walks its share itself, after its dense loop: the sums meet the dense partial sums in LDS and leave in the
-// tile's own epilogue.  No chunk workgroups (each of them 4-8 us of dependent memory round trips in a slot a
-// dense workgroup could hold: with two or three 512-thread workgroups per CU they were the first round of
-// the grid and cost a 13B s45 decoder layer 50 us at 8 rows, 80 at 16), no global atomics of their own, no
-// row search over rows[] (the tile's 65 row pointers are staged with the codebooks).
+// CSR rows FOLDED into the dense workgroups (the fused small launch of the split matrix-core kernel, 5..16 rows at 4
+// bits, 9..16 at 3; replaces SPMV_ATOMIC_BATCHED, squeezellm/quant_cuda_kernel.cu:1061-1089, there).  CSR rows are
+// output channels, so the non-zeros of a 64-column dense tile are ONE contiguous range of cols / vals,
+// rows[col0] .. rows[col0 + 64); the workgroups that share the tile (its K slices / pieces) cut that range in
+// proportion to their units of K, and each walks its share itself, after its dense loop: the sums meet the dense
+// partial sums in LDS and leave in the tile's own epilogue.  No chunk workgroups (each of them 4-8 us of dependent
+// memory round trips in a slot a dense workgroup could hold: with two 512-thread workgroups per CU they and the
+// top-X slabs were the first round of the grid, the dense workgroups that found no slot a second one -- 50 us of a
+// 13B s45 decoder layer at 8 rows, 80 at 16), no global atomics of their own, no search over rows[] (the tile's 65
+// row pointers are staged with the codebooks).
 //
-// The walk: lane = (group, batch row); a group of R lanes (R = the batch rounded up to a power of two) takes
-// a contiguous run of the share and walks it one non-zero per step -- column and value are read by all R
-// lanes (one address), x[row][column] is a gather per lane, the running sum leaves with ONE LDS add per
-// (CSR row, batch row) when the run crosses into the next row.  The cost of a non-zero does not depend on
-// the batch (the segmented scan of csr_role cost ~30 dependent instructions per batch row and run).
+// The walk: lane = (group, batch row); a group of R lanes (R = the batch rounded up to a power of two) takes a
+// contiguous run of the share and walks it one non-zero per step -- column, local row and value come out of LDS (one
+// address per group), the vec value is one load per lane: out of a TRANSPOSED copy of vec (xT[k][R], written by
+// sqllm_transpose_small into the caller's workspace) the R lanes read one line per non-zero; without a workspace each
+// lane gathers from its own row of vec, a line per non-zero AND batch row (~2.5 cycles of the CU's vector memory pipe
+// each: 46 / 100 us of a 13B layer at 8 / 16 rows, profiles/r05_fold_staged_gathers.txt).  The running sum leaves
+// with ONE LDS add per (CSR row, batch row) where the run crosses into the next row.
 //   srp   LDS, rows[min(col0 + i, N)] for i = 0 .. 64 (staged by the caller, visible)
-//   ssum  LDS [16][64] floats, zero: sums by (batch row, local column) -- the layout of an epilogue slab
+//   ssum  LDS [16][kFoldSumStride] floats, zero: sums by (batch row, local column)
+//   stage LDS, 2 * kFoldStage words, free until the caller's epilogue (its cross-wave slabs): the share's columns
+//         (+ local rows) and values, one coalesced round of loads for all of them -- the first PRE per thread are
+//         loaded BEFORE the dense loop (pre_c / pre_v / pre_r: element tid + T i of the share)
+// Measured on the way (profiles/r05_*): the walk as a chunk of exposed round trips at the end of every workgroup
+// without staging (r05_fold_first_run), ONE wave walking beside seven decoding (r05_walker_wave: the walk is serial
+// per lane group), 40 gathers per round trip (r05_walk_one_round), the batch tiles and the column-lane kernel folded
+// the same way (2..4 rows: slower than their chunk role, which keeps that job).
 // ------------------------------------------------------------------------------------------------
 constexpr int kFoldRp = 128;   // staged row pointers (65 used; thread t stores entry t % 128)
 constexpr int kFoldSumStride = kTileN + 1;  // floats between the batch rows of the sums: a group's lanes (one batch row each) add to different banks
@@ -516,84 +516,7 @@ __device__ __forceinline__ int fold_share(int len, int u, int units_total, unsig
   return u >= units_total ? len : (int)__umulhi((unsigned)len, (unsigned)u * inv);
 }
 
-template <int T, int U = 8>  // T: threads of the team that walks (tid = 0 .. T - 1), U: non-zeros in flight per lane
-__device__ __forceinline__ void csr_tile_fold(const float* __restrict__ x, const int* __restrict__ cols,
-                                              const float* __restrict__ vals, int K, int b0, int nb, int u_beg,
-                                              int u_end, int units_total, const int* srp, float* ssum, int tid) {
-  const int lo = srp[0];
-  const int len = srp[kTileN] - lo;
-  if (len <= 0) return;
-  const unsigned inv = 0xFFFFFFFFu / (unsigned)units_total;
-  const int sbeg = lo + fold_share(len, u_beg, units_total, inv);
-  const int send = lo + fold_share(len, u_end, units_total, inv);
-  const int n = send - sbeg;
-  if (n <= 0) return;
-  const int lr = nb <= 2 ? 1 : nb <= 4 ? 2 : nb <= 8 ? 3 : 4;  // log2 of the lanes per group
-  const int per = (n + (T >> lr) - 1) >> (__builtin_ctz(T) - lr);  // non-zeros per group, T >> lr groups
-  const int bl = tid & ((1 << lr) - 1);
-  int e = sbeg + (tid >> lr) * per;
-  int g_hi = e + per;
-  if (g_hi > send) g_hi = send;
-  if (e >= g_hi) return;
-  // the CSR row of the run's first non-zero: the largest r with srp[r] <= e
-  int r = 0;
-#pragma unroll
-  for (int s = kTileN / 2; s > 0; s >>= 1)
-    if (srp[r + s] <= e) r += s;
-  int rend = srp[r + 1];
-  const bool live = bl < nb;
-  const float* xl = x + (size_t)(b0 + (live ? bl : nb - 1)) * K;
-  float* srow = ssum + bl * kTileN;
-  float acc = 0.f;
-  // columns and values of a batch are loaded beside the gathers of the batch before (one round trip per batch)
-  int c[U];
-  float v[U];
-  auto load_cv = [&](int e0, int (&cc)[U], float (&vv)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int ee = e0 + u < g_hi ? e0 + u : g_hi - 1;  // (clamped re-reads; skipped below)
-      cc[u] = cols[ee];
-      vv[u] = vals[ee];
-    }
-  };
-  load_cv(e, c, v);
-  for (; e < g_hi; e += U) {
-    float xv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) xv[u] = xl[c[u]];
-    int c2[U];
-    float v2[U];
-    load_cv(e + U, c2, v2);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int eu = e + u;
-      if (eu < g_hi) {
-        if (eu >= rend) {  // the run enters another row (empty rows in between are skipped)
-          if (live) atomicAdd(srow + r, acc);
-          acc = 0.f;
-          do {
-            ++r;
-            rend = srp[r + 1];
-          } while (eu >= rend && r < kTileN - 1);
-        }
-        acc = __builtin_fmaf(v[u], xv[u], acc);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      c[u] = c2[u];
-      v[u] = v2[u];
-    }
-  }
-  if (live) atomicAdd(srow + r, acc);
-}
-
-// The same walk for a whole workgroup with the share's columns and values STAGED in LDS first (the fused small launch of
-// the split matrix-core kernel, after its dense loop): one coalesced round of loads for all of them -- the first PRE per
-// thread may have been loaded before the dense loop (pre_c / pre_v: element tid + T i of the share, clamped re-reads past
-// it) -- then every group gathers U values of vec per round trip.  Every thread of the workgroup must call it (barriers).
-//   stage  LDS, 2 * kFoldStage words, free until the caller's epilogue (its cross-wave slabs)
-constexpr int kFoldStage = 4096;  // non-zeros staged per pass
+constexpr int kFoldStage = 4096;  // non-zeros staged per pass (a larger share: more passes)
 
 // the share [sbeg, send) of this piece in the tile's non-zeros (absolute indices into cols / vals)
 __device__ __forceinline__ void fold_piece_share(const int* srp, int u_beg, int u_end, int units_total, int* sbeg, int* send) {
@@ -605,10 +528,6 @@ __device__ __forceinline__ void fold_piece_share(const int* srp, int u_beg, int 
   *send = lo + fold_share(len, u_end, units_total, inv);
 }
 
-//   xT     vec TRANSPOSED for this pass of rows, xT[k][2^lr] (sqllm_transpose_small; rows past the batch zero), or null:
-//          a group's lanes then read ONE line per non-zero; gathers from vec itself cost a line per non-zero AND batch row
-//          (~2.5 cycles of the CU's vector memory pipe each: 46 / 100 us of a 13B s45 decoder layer at 8 / 16 rows,
-//          profiles/r05_fold_staged_gathers.txt)
 // local rows of N non-zeros (absolute indices ea[]): the largest r with srp[r] <= ea, the N searches side by side
 template <int N>
 __device__ __forceinline__ void fold_rows_of(const int* srp, const int (&ea)[N], int (&r)[N]) {
@@ -624,6 +543,7 @@ __device__ __forceinline__ void fold_rows_of(const int* srp, const int (&ea)[N],
   }
 }
 
+// The walk itself (every thread of the workgroup must call it: barriers).  U = gathers of vec per lane and round trip;
 // pre_r: the local rows of the preloaded non-zeros, six bits each (fold_rows_of, worked out before the dense loop as well)
 template <int T, int U, int PRE>
 __device__ __forceinline__ void csr_tile_fold_staged(const float* __restrict__ x, const float* __restrict__ xT, const int* __restrict__ cols,

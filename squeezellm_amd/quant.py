@@ -189,23 +189,26 @@ class QuantLinearLUTFused(QuantLinearLUT):
         self.__dict__["_folded"] = (key, out)
         return out
 
-    def _descriptor(self, batch: int, dev: int, stream: int):
-        """The pre-marshalled sqllm_linear of this module for (batch, device, stream): every persistent field filled in
-        once -- weights, codebook, the (folded) sparse operands, bias, workspace -- and re-used call after call; only
-        vec / mul change per call.  Rebuilt when a buffer is replaced or written in place (object identity + version
-        counter of every buffer it was built from)."""
+    def _descriptor(self, dev: int, stream: int):
+        """The pre-marshalled sqllm_linear of this module for (device, stream): every persistent field filled in once --
+        weights, codebook, the (folded) sparse operands, bias -- and re-used call after call; vec / mul, the batch and the
+        workspace pointer are set per call (ONE entry per device and stream whatever row counts arrive: an entry per
+        batch would pin a superseded workspace each and grow without bound under variable prompt lengths).  Rebuilt when
+        a buffer is replaced, moved or written in place (identity, storage and version counter of every buffer it was
+        built from) or when a routing attribute changes (fold_topx, include_sparse, topX, numvals)."""
         # (straight from the module's buffer dict: nn.Module.__getattr__ costs ~0.5 us per buffer, ten times a dict lookup)
         bufs = self.__dict__["_buffers"]
-        key = tuple((id(t), t._version) for t in bufs.values() if t is not None)
+        key = (tuple((id(t), t.data_ptr(), t._version) for t in bufs.values() if t is not None),
+               self.fold_topx, self.include_sparse, self.topX, self.numvals)
         cache = self.__dict__.setdefault("_desc", {})
-        hit = cache.get((batch, dev, stream))
+        hit = cache.get((dev, stream))
         if hit is not None and hit[0] == key:
             return hit[1]
         capturing = torch.cuda.is_current_stream_capturing()
         K, N = self.infeatures, self.outfeatures
         lin = _lib.SqllmLinear()
         o = lin.op
-        o.bits, o.batch, o.K, o.N = self.bits, batch, K, N
+        o.bits, o.K, o.N = self.bits, K, N
         o.qweight, o.lookup_table = self.qweight.data_ptr(), self.lookup_table.data_ptr()
         if self.include_sparse and self.numvals > 0:
             self._check_csr_once()
@@ -220,12 +223,10 @@ class QuantLinearLUTFused(QuantLinearLUT):
             if self.include_sparse and self.topX > 0:  # independent of the CSR term (which may be empty)
                 o.full_rows, o.full_row_indices, o.topX = self.full_rows.data_ptr(), self.full_row_indices.data_ptr(), self.topX
         lin.bias = None if self.bias is None else self.bias.data_ptr()
-        ws = self._workspace(batch, self.qweight.device)
-        lin.workspace = ws.data_ptr()
-        entry = (key, (lin, ctypes.byref(lin), ws, keep))
+        entry = (key, (lin, ctypes.byref(lin), keep))
         # (while a stream is capturing, the folded CSR and the CSR check are deferred: do not pin that state)
         if not (capturing and self.include_sparse):
-            cache[(batch, dev, stream)] = entry
+            cache[(dev, stream)] = entry
         return entry[1]
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -240,8 +241,12 @@ class QuantLinearLUTFused(QuantLinearLUT):
         rows = x2.shape[0]
         dev = x.get_device()
         out = torch.empty((rows, N), dtype=torch.float16, device=x.device)
-        lin, ref, _ws, _keep = self._descriptor(0 if rows == 1 else rows, dev, quant_cuda._raw_stream(dev))
-        lin.op.vec, lin.op.mul = x2.data_ptr(), out.data_ptr()
+        lin, ref, _keep = self._descriptor(dev, quant_cuda._raw_stream(dev))
+        batch = 0 if rows == 1 else rows
+        ws = self._workspace(batch, self.qweight.device)  # (one buffer per device and stream, grown to the largest batch seen)
+        o = lin.op
+        o.batch, o.vec, o.mul = batch, x2.data_ptr(), out.data_ptr()
+        lin.workspace = ws.data_ptr()
         quant_cuda._launch(quant_cuda._fn("sqllm_linear_f16"), dev, (ref,))
         return out.reshape(*x.shape[:-1], N)
 

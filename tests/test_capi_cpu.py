@@ -109,7 +109,7 @@ def test_plan_geometry():
     assert pm["groups_per_wave"] % 32 == 0 and pm["dense_blocks"] <= 512
     # the fused small launch (matrix cores up to 16 rows): the CSR term is walked by the dense workgroups themselves
     # (csr_tile_fold: one wave of each) -- no chunk workgroups in the grid, only the top-X slabs; batch 1, the batch tiles
-    # and 17+ rows keep the chunk role (option csr_fold = 1 folds it into the batch tiles too)
+    # and 17+ rows keep the chunk role
     # (planned as launched with a workspace: vec transposed, the top-X slabs shared by few workgroups of several slabs each --
     # an op alone in its launch: up to 24, or 16 from 25 slabs; in a group 8 / 16 per op -- and the dense ranges cut for the
     # slots they leave: ONE round of workgroups in all)
@@ -120,9 +120,6 @@ def test_plan_geometry():
     for b in (1, 17):
         assert _lib.plan_query(4, 5120, 13824, nnz=330_000, topX=10, batch=b)["csr_blocks"] == -(-330_000 // 1024)
     assert _lib.plan_query(4, 5120, 5120, nnz=128_000, topX=10, batch=2)["csr_blocks"] == 125
-    _lib.set_option("csr_fold", 1)
-    assert _lib.plan_query(4, 5120, 5120, nnz=128_000, topX=10, batch=2)["csr_blocks"] == 0
-    _lib.set_option("csr_fold", 0)
     total = pm["col_tiles"] * (5120 // 8)
     assert pm["dense_blocks"] * pm["groups_per_wave"] >= total > (pm["dense_blocks"] - 1) * pm["groups_per_wave"]
     pw = _lib.plan_query(4, 5120, 13824, batch=2048)  # 32 x 27 = 864 units: 3 whole rounds + 96 units in two K slices of 320

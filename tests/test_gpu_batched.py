@@ -207,12 +207,18 @@ def test_wide_form_at_13b_size_agrees_with_the_batch1_operator(qc, gpu, bits, ve
     name = f"vecquant{bits}matmul_spmv_hybrid_nuq_perchannel"
     args = (lay["rows"], lay["cols"], lay["vals"])
     getattr(qc, name + "_batched")(*args, x, lay["full_rows"], lay["full_row_indices"], y, N, lay["qweight"], lay["lookup_table"])
-    for r in (0, 63, 64, 300, 575, 599):
+    sample = (0, 63, 64, 300, 575, 599)
+    for r in sample:
         yr = y0[r].clone()
         getattr(qc, name)(*args, x[r].contiguous(), lay["full_rows"], lay["full_row_indices"], yr, N, lay["qweight"], lay["lookup_table"])
         torch.cuda.synchronize()
         err = float((y[r] - yr).abs().max() / yr.abs().max())
         assert err <= 2e-5, (r, err)
+    # ... and the same rows against the ORACLE itself (the C restatement, fp64 accumulation: seconds for six rows)
+    case = dict(K=K, N=N, bits=bits, **{k: lay[k].cpu().numpy() for k in ("qweight", "lookup_table", "rows", "cols", "vals", "full_rows", "full_row_indices")})
+    idx = list(sample)
+    ref = H.c_matvec(H.c_oracle(), case, x[idx].cpu().numpy(), y0[idx].cpu().numpy(), True)
+    assert H.rel_err(y[idx].cpu().numpy(), ref) <= TOL_FP64
 
 
 def _routing(mfma_min, cols_min, cols_max):
@@ -298,6 +304,7 @@ def test_three_batched_paths_agree(qc, gpu, bits):
     t = H.to_torch(case, gpu)
     for B in (3, 24):
         x = torch.randn((B, 2048), device=gpu)
+        ref = H.oracle_ref(case, x.cpu().numpy(), np.zeros((B, 1024), np.float32), "hybrid")
         outs = []
         try:
             for routing in ((1 << 30, 1 << 30, 1 << 30), (1 << 30, 1, 1 << 30), (1, 1 << 30, 1 << 30)):
@@ -306,6 +313,7 @@ def test_three_batched_paths_agree(qc, gpu, bits):
                 H.call_op(qc, t, x, y, "hybrid", True)
                 torch.cuda.synchronize()
                 outs.append(y.cpu().numpy())
+                assert H.rel_err(outs[-1], ref) <= TOL_FP64, (B, routing)  # every leg against the oracle, not against leg 0
         finally:
             _routing(0, 0, 0)
         assert H.rel_err(outs[1], outs[0]) <= 1e-5 and H.rel_err(outs[2], outs[0]) <= 1e-5
@@ -321,6 +329,7 @@ def test_both_batched_paths_agree(qc, gpu, bits):
     case = H.make_case(bits, 2048, 1024, sparse=0.0045, topX=10, heavy_rows=4, seed=5)
     t = H.to_torch(case, gpu)
     x = torch.randn((24, 2048), device=gpu)
+    ref = H.oracle_ref(case, x.cpu().numpy(), np.zeros((24, 1024), np.float32), "hybrid")
     outs = []
     try:
         for min_batch in (1 << 30, 1):
@@ -329,6 +338,7 @@ def test_both_batched_paths_agree(qc, gpu, bits):
             H.call_op(qc, t, x, y, "hybrid", True)
             torch.cuda.synchronize()
             outs.append(y.cpu().numpy())
+            assert H.rel_err(outs[-1], ref) <= TOL_FP64, min_batch  # each leg against the oracle
     finally:
         _lib.set_option("mfma_min_batch", 0)
     assert H.rel_err(outs[1], outs[0]) <= 1e-5

@@ -258,6 +258,7 @@ def test_fused_forward_keeps_one_workspace_across_batch_sizes(gpu):
         y = mod(x if rows > 1 else x.reshape(1, 1, K)).reshape(rows, N)
         _check_fp16(y.cpu().numpy(), _exact(npl, x.cpu().numpy(), "hybrid"))
         assert len(mod._ws) == 1
+        assert len(mod._desc) == 1  # (ONE descriptor per device and stream, not one per row count pinning a superseded workspace each)
         sizes.append(next(iter(mod._ws.values())).numel())
         assert int(next(iter(mod._ws.values())).count_nonzero()) == 0
     assert sizes == sorted(sizes) and sizes[-1] == 8 * 12 * N
@@ -351,3 +352,34 @@ def test_fused_linear_sees_operands_refreshed_in_place(gpu):
     torch.cuda.synchronize()
     assert not torch.allclose(y0, y1, atol=1e-3)
     assert torch.allclose(y1, want, atol=2e-3 * float(want.abs().max())), float((y1 - want).abs().max())
+
+
+def test_fused_descriptor_follows_routing_attributes_and_replaced_storage(gpu):
+    """the cached descriptor is keyed on the buffers' identity, STORAGE and version and on the routing attributes --
+    `mod.fold_topx = False` after a first forward takes effect, and `buf.data = other` (same object, same version counter,
+    new storage) does not leave the kernel reading the old allocation."""
+    import torch
+
+    from squeezellm_amd import quant, synth
+
+    lay = synth.make_layer(512, 256, 4, sparse_frac=0.01, topX=6, heavy_rows=2, device=gpu, seed=78)
+    mod = quant.QuantLinearLUT.from_operands(lay)
+    mod.__class__ = quant.QuantLinearLUTFused
+    x = torch.randn(3, 512, device=gpu, dtype=torch.float16)
+    y0 = mod(x).float()
+    lin0 = next(iter(mod._desc.values()))[1][0]
+    assert lin0.op.topX == 0  # folded: one CSR term
+    mod.fold_topx = False
+    y1 = mod(x).float()
+    lin1 = next(iter(mod._desc.values()))[1][0]
+    assert lin1.op.topX == 6 and lin1.op.full_rows == mod.full_rows.data_ptr()  # rebuilt: the top-X rows passed separately
+    assert torch.allclose(y0, y1, atol=2e-3 * float(y0.abs().max()))
+    new_lut = (mod.lookup_table * 2.0).clone()
+    mod.lookup_table.data = new_lut  # same tensor object and version, another allocation
+    y2 = mod(x).float()
+    lin2 = next(iter(mod._desc.values()))[1][0]
+    assert lin2.op.lookup_table == new_lut.data_ptr()
+    ref = quant.QuantLinearLUT.from_operands(dict(lay, lookup_table=new_lut))
+    want = ref(x).float()
+    torch.cuda.synchronize()
+    assert torch.allclose(y2, want, atol=2e-3 * float(want.abs().max())), float((y2 - want).abs().max())

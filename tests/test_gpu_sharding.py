@@ -113,3 +113,21 @@ def test_bench_distributed_modes_run_on_one_rccl_rank(gpu, mode, env):
         assert line["pipeline_tick_captured"] is True  # (one rank: the whole tick is always captured)
     else:
         assert line["column_parallel"]["graph_captured"] in (True, False)
+
+
+def test_bench_8gpu_command_dry_run_on_one_rank(gpu):
+    """`python bench.py --gpus 8 --config 65b-w3-s45` under SQLLM_BENCH_FORCE_DIST=1 on ONE rank runs the code
+    path the 8-GPU command takes (layer-sharded ring pipeline, one RCCL all-gather per tick, the tick captured) and says so."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    e = dict(os.environ, SQLLM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29977", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    cmd = [sys.executable, os.path.join(H.ROOT, "bench.py"), "--gpus", "8", "--config", "65b-w3-s45", "--layers", "2", "--steps", "3", "--warmup", "1",
+           "--repeats", "2", "--no-cpu-baseline", "--no-roofline", "--no-sub-records"]
+    r = subprocess.run(cmd, cwd=H.ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["parallelism"].startswith("pp8") and "DRY RUN" in line["config"]["parallelism"]
+    assert line["config"]["rccl_ranks"] == 1 and line["pipeline_tick_captured"] is True and line["value"] > 0
