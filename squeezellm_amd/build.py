@@ -30,7 +30,11 @@ EXPERIMENT_SOURCES = ["experimental/sqllm_ablation.hip", "experimental/sqllm_str
 HEADERS = [os.path.join(CSRC, h) for h in ("sqllm_kernels.h", "sqllm_decode.h", "sqllm_roles.h", "sqllm_fused.h", "sqllm_split_common.h", "sqllm_host.h")] + [os.path.join(INCLUDE, "sqllm_hip.h")]
 EXPERIMENT_HEADERS = [os.path.join(EXPERIMENTAL, h) for h in ("sqllm_pass.h", "sqllm_pass_api.h")]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# -amdgpu-kernarg-preload-count: the kernels' leading explicit arguments (the vec pointer) arrive in SGPRs instead of
+# through the first scalar load (gfx950 preloads up to 16 dwords; the by-value descriptor block cannot be preloaded):
+# mean kernel duration of the 7B batch-1 launches -2.5 %, same-box A/B profiles/r05_kernarg_preload_ab.txt
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 class HipccMissing(RuntimeError):

@@ -243,6 +243,8 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
     }
     __builtin_amdgcn_sched_barrier(0);
   };
+  // (Measured and dropped twice, profiles/r05_walker_wave.txt and r05_tickets.txt: the groups handed out by an LDS ticket
+  // instead of round-robin -- the waves of a workgroup leave this loop up to 2.8 us apart -- 2-4 % slower.)
   for (int g = 0; g < n_g; g += 2) {  // the wave's groups: wave, wave + WAVES, ...
     const int t = wave + WAVES * g;
     if constexpr (NPH == 1) {

@@ -729,7 +729,7 @@ __device__ __forceinline__ void topx_role(const XT* x, AT* __restrict__ y,
           float sum = 0.f;
 #pragma unroll
           for (int w = 0; w < T / 64; ++w) sum += lds[(r * (T / 64) + w) * 16 + cc];
-          acc_add(y + (size_t)(b0 + bp + r) * N + full_idx[cc], sum);
+          acc_add(y + (size_t)(b0 + bp + r) * N + dst, sum);  // (cc == c: this thread's own early-loaded index)
         }
       }
     }
