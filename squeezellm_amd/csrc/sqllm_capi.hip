@@ -670,7 +670,8 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     // k for all the batch rows); without, they gather from vec itself.
     bool any_sparse = false;
     for (int i = 0; i < n; ++i) any_sparse = any_sparse || (ops[i].nnz > 0 && ops[i].rows) || (ops[i].full_rows && ops[i].topX > 0);
-    const bool want_xT = any_sparse && ops[0].batch > 0 && ops[0].K > 0 && ops[0].vec && knobs().sparse_transpose.load(std::memory_order_relaxed);
+    const bool want_xT = any_sparse && ops[0].batch > 0 && ops[0].K > 0 && ops[0].vec && (reinterpret_cast<uintptr_t>(ops[0].vec) & 15u) == 0 &&
+                         knobs().sparse_transpose.load(std::memory_order_relaxed);  // (the transposition reads vec 16 bytes at a time)
     const int64_t xt_bytes = want_xT ? sqllm::transpose_small_bytes(ops[0].batch, ops[0].K) : 0;
     float* xT = nullptr;
     struct Scratch {  // the workspace-less names: stream-ordered scratch, as for the wider batches (never inside a capture:

@@ -785,29 +785,32 @@ __global__ void __launch_bounds__(256) sqllm_transpose_vec(const float* __restri
   }
 }
 
-// Small batches (2..16 rows): xT[k][rp], rp = the batch rounded up to a power of two, rows past the batch zero -- one
-// thread per k, coalesced reads along k, one 8..64-byte store.  Read by the folded CSR walk (csr_tile_fold_staged).
+// Small batches (2..16 rows): xT[k][rp], rp = the batch rounded up to a power of two, rows past the batch zero.  Read by
+// the folded CSR walk and the top-X slabs of the fused small launch (csr_tile_fold_staged, topx_role_xt).  The kernel
+// sits in front of every such launch, so its own round trips count: a thread = (batch row, four consecutive k's) -- ONE
+// 16-byte load (a wave reads a whole line of each of its rows) and four 4-byte stores that a wave lays down as whole
+// lines.  (One thread per k with a load per batch row: 5.6 us per launch in the kernel trace, profiles/r05_kt_13b_rows.summary.txt.)
 __global__ void __launch_bounds__(256) sqllm_transpose_small(const float* __restrict__ x, float* __restrict__ xT, int batch, int K, int lr) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= K) return;
-  const int rp = 1 << lr;
-  float v[16];
-#pragma unroll
-  for (int b = 0; b < 16; ++b) v[b] = (b < batch && b < rp) ? x[(size_t)b * K + k] : 0.f;
-  float* dst = xT + ((size_t)k << lr);
-  if (rp == 2) {
-    *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
-  } else {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (4 * q < rp) *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-  }
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  const unsigned rp = 1u << lr;
+  const unsigned b = t & (rp - 1u);
+  const unsigned k = (t >> lr) * 4u;
+  if (k >= (unsigned)K) return;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (b < (unsigned)batch) v = *reinterpret_cast<const f32x4*>(x + (size_t)b * K + k);  // (K is a multiple of 32)
+  float* dst = xT + ((size_t)k << lr) + b;
+  dst[0] = v.x;
+  dst[rp] = v.y;
+  dst[2 * rp] = v.z;
+  dst[3 * rp] = v.w;
 }
 
 hipError_t transpose_small(const float* x, float* xT, int batch, int K, hipStream_t stream, hipEvent_t ev_start) {
   const int lr = batch <= 2 ? 1 : batch <= 4 ? 2 : batch <= 8 ? 3 : 4;
-  if (ev_start) hipExtLaunchKernelGGL(sqllm_transpose_small, dim3((K + 255) / 256), dim3(256), 0, stream, ev_start, nullptr, 0, x, xT, batch, K, lr);
-  else hipLaunchKernelGGL(sqllm_transpose_small, dim3((K + 255) / 256), dim3(256), 0, stream, x, xT, batch, K, lr);
+  const unsigned threads = (unsigned)(K / 4) << lr;
+  const dim3 grid((threads + 255u) / 256u);
+  if (ev_start) hipExtLaunchKernelGGL(sqllm_transpose_small, grid, dim3(256), 0, stream, ev_start, nullptr, 0, x, xT, batch, K, lr);
+  else hipLaunchKernelGGL(sqllm_transpose_small, grid, dim3(256), 0, stream, x, xT, batch, K, lr);
   return hipGetLastError();
 }
 

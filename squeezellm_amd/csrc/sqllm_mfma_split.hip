@@ -258,7 +258,7 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
   SQLLM_PROBE(tl, 2, tid == 0);  // wave 0 done decoding
   SQLLM_PROBE(tl, 7, tid == T - 64);  // the last wave done decoding
   if constexpr (FOLD) {
-    if (fold)
+    if (fold)  // (walked BEFORE the loop by every other CU-load of workgroups, so that neighbours on a CU alternate: no gain -- profiles/r05_walk_first.txt)
       csr_tile_fold_staged<T, 20, kFoldPre>(x, xT, csr_cols, csr_vals, K, m0, batch - m0 < 16 ? batch - m0 : 16, sp_beg, sp_end, srp, ssum,
                                            reinterpret_cast<int*>(slabs), tid, pre_c, pre_v, pre_r, tl);
   }

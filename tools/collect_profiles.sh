@@ -50,6 +50,11 @@ sum /tmp/prof_pmc_batched_mfma > $R/gpurun_out/${tag}_pmc_batched_mfma.summary.t
 # small batches: batch tiles vs column-lane kernel, 13B gate/up shape, dense and hybrid
 run kt_small_batches --kernel-trace --stats -d /tmp/prof_kt_small -o x -- python $R/tools/batch_sweep.py --paths tile,cols --batches 2,4,8 --reps 2 --sparse 0 --topx 0
 sum /tmp/prof_kt_small > $R/gpurun_out/${tag}_kt_small_batches.summary.txt
+# configs[3], 13B w4 s45 decoder layer by batch rows: kernel trace at 8 / 16 rows and the same-box A/B against the previous round's build
+run kt_13b_rows --kernel-trace --stats -d /tmp/prof_kt_13b_rows -o x -- python $R/tools/experiments/small_batch_r05.py --rows 8,16 --no-breakdown
+sum /tmp/prof_kt_13b_rows > $R/gpurun_out/${tag}_kt_13b_rows.summary.txt
+(cd $R && timeout 300 python tools/experiments/small_batch_r05.py --rows 1,2,4,5,6,8,12,16 2>/dev/null | grep '^{' > gpurun_out/${tag}_small_batch_ab.txt
+ [ -f squeezellm_amd/ab/libr04.so ] && SQLLM_LIB=$R/squeezellm_amd/ab/libr04.so timeout 300 python tools/experiments/small_batch_r05.py --rows 1,2,4,5,6,8,12,16 2>/dev/null | grep '^{' >> gpurun_out/${tag}_small_batch_ab.txt)
 # un-profiled bench lines, all configs, one box
 cd $R
 for c in 7b-w4-s0 7b-w3-s45 7b-w4-s45 7b-w3-s0 13b-w4-s45 65b-w3-s45; do

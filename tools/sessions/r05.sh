@@ -181,5 +181,30 @@ s18)
   (SQLLM_LIB=$PWD/squeezellm_amd/ab/libhead.so timeout 300 python $E --rows 8,16 --dense-only 2>&1 | grep '^{') >> gpurun_out/r05_s18.txt
   cat gpurun_out/r05_s18.txt
   ;;
-*) echo "usage: $0 s1..s18"; exit 2;;
+s19)
+  # round 5, session 19: the 16-byte transposition kernel; batch-1 A/B against the round-4 build (SQLLM_LIB)
+  mkdir -p gpurun_out
+  (timeout 600 python -m pytest tests/test_gpu_batched.py tests/test_gpu_decoder_layer.py tests/test_gpu_nonfinite.py tests/test_gpu_workspace.py -m gpu -q 2>&1 | tail -3) > gpurun_out/r05_s19.txt
+  E=tools/experiments/small_batch_r05.py
+  (timeout 300 python $E --rows 5,8,12,16 2>&1 | grep '^{') >> gpurun_out/r05_s19.txt
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libr04.so timeout 300 python $E --rows 5,8,12,16 2>&1 | grep '^{') >> gpurun_out/r05_s19.txt
+  for rep in 1 2; do for v in r04 head; do for c in 7b-w4-s0 7b-w4-s45 7b-w3-s45; do
+  L=$PWD/squeezellm_amd/ab/lib$v.so; [ $v = head ] && L=$PWD/squeezellm_amd/libsqllm_hip.so
+  (echo -n "$v "; SQLLM_LIB=$L timeout 200 python bench.py --config $c --no-cpu-baseline --no-sub-records 2>/dev/null | grep "^{") >> gpurun_out/r05_s19_batch1_ab.txt; done; done; done
+  cat gpurun_out/r05_s19.txt; wc -l gpurun_out/r05_s19_batch1_ab.txt
+  ;;
+s20)
+  # round 5, session 20: every other CU-load of workgroups walks its CSR share BEFORE its dense loop; batch-1 A/B against the round-4 build
+  mkdir -p gpurun_out
+  (timeout 600 python -m pytest tests/test_gpu_batched.py tests/test_gpu_decoder_layer.py tests/test_gpu_nonfinite.py tests/test_gpu_workspace.py -m gpu -q 2>&1 | tail -3) > gpurun_out/r05_s20.txt
+  E=tools/experiments/small_batch_r05.py
+  (timeout 300 python $E --rows 5,8,12,16 --sets "default;small_walk_first=0" 2>&1 | grep '^{') >> gpurun_out/r05_s20.txt
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libr04.so timeout 300 python $E --rows 5,8,12,16 2>&1 | grep '^{') >> gpurun_out/r05_s20.txt
+  (timeout 300 python $E --bits 3 --rows 9,16 --sets "default;small_walk_first=0" 2>&1 | grep '^{') >> gpurun_out/r05_s20.txt
+  for rep in 1 2; do for v in r04 head; do for c in 7b-w4-s0 7b-w4-s45 7b-w3-s45; do
+  L=$PWD/squeezellm_amd/ab/lib$v.so; [ $v = head ] && L=$PWD/squeezellm_amd/libsqllm_hip.so
+  (echo -n "$v "; SQLLM_LIB=$L timeout 200 python bench.py --config $c --no-cpu-baseline --no-sub-records 2>/dev/null | grep "^{") >> gpurun_out/r05_s20_batch1_ab.txt; done; done; done
+  cat gpurun_out/r05_s20.txt; wc -l gpurun_out/r05_s20_batch1_ab.txt
+  ;;
+*) echo "usage: $0 s1..s20"; exit 2;;
 esac
