@@ -293,9 +293,10 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     takes the range at its word.
  *   "cols_groups"     1 (default): a GROUP of ops over one vec (sqllm_launch_group) may take the column-lane kernel
  *                     too, as one launch, judged by the sum of its columns; 0: groups stay on the batch tiles
- *   "sparse_transpose" 1 (default): the CSR term of a wide-batch op reads a transposed copy of vec
- *                     (lane = batch row, coalesced); 0: it gathers from vec itself, as it does
- *                     anyway when no scratch can be had
+ *   "sparse_transpose" 1 (default): the sparse terms of a batched op (mfma_min_batch rows and more) read a transposed copy of
+ *                     vec (lane = batch row, coalesced) out of the caller's workspace (sqllm_launch_ws) or, for the
+ *                     workspace-less names, out of stream-ordered scratch; 0: they gather from vec itself, as they do
+ *                     anyway when neither can be had
  *                     The scratch is stream-ordered (hipMallocAsync / hipFreeAsync on the caller's
  *                     stream, K x ceil64(batch) floats per op or group); on first use per device the
  *                     library raises the release threshold of the device's DEFAULT memory pool to
@@ -312,8 +313,10 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     products kept (fp32-class results, 2.7 x the matrix rate of the fp32 instruction); 0: the fp32 matrix
  *                     instruction (bit-for-bit an fp32 FMA chain per output)
  *   "mfma_fuse_small" 1 (default, with mfma_split): from mfma_min_batch up to 16 rows an op -- or a whole GROUP of ops over one vec
- *                     (sqllm_launch_group) -- is ONE launch of the split matrix-core kernel with its CSR / top-X workgroups in
- *                     the same grid; 0: one launch per op plus a launch for its sparse terms (as from 17 rows on)
+ *                     (sqllm_launch_group) -- is ONE launch of the split matrix-core kernel: every dense workgroup walks the CSR
+ *                     non-zeros of its own 64 output channels (no chunk workgroups), the top-X slabs ride in the same grid; with a
+ *                     workspace (or, eagerly, scratch) a small kernel in front transposes vec for those two (K < 2^26);
+ *                     0: one launch per op plus a launch for its sparse terms (as from 17 rows on)
  *   "mfma_fuse_sparse" 1 (default, with mfma_split): from 17 rows up to the wide form an op's CSR / top-X workgroups run in the grid of
  *                     its dense launch -- always up to 64 rows (33-64 rows: as two 32-row passes if they outnumber the CUs),
  *                     beyond that while they are fewer than the CUs; 0: a launch of their own first
@@ -330,6 +333,11 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     QuantLinearLUT.forward passes -- then costs five partial products instead of six); below, or without
  *                     scratch (scratch_in_capture = 0 while capturing, allocation failure), every wave splits its values in
  *                     registers and K slices add atomically; a huge value: never.
+ *   "small_wgs_per_cu" 0 (default: 2): dense workgroups per CU the planner of the fused small launch (mfma_min_batch .. 16 rows)
+ *                     aims at -- one round of workgroups, as many as the kernel's registers admit at once
+ *   "small_reserve_topx" 0 (default): with a transposed vec at hand the dense ranges of that launch are always planned for the
+ *                     slots the (8-24) top-X workgroups leave; 1 does the same without one (one workgroup per top-X slab:
+ *                     measured slower, profiles/r05_small_split_reserve.txt)
  *   "validate_csr"    debugging aid, default 0.  1 = before every launch that carries a CSR term,
  *                     check ON THE DEVICE that rows[] is non-decreasing with rows[0] == 0 and
  *                     rows[N] == nnz, and return SQLLM_E_SPARSE otherwise.  Blocks the host (one

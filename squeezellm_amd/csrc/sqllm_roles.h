@@ -232,7 +232,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
       const int bp0 = b0 + pb;
       if (pb) {  // the tile again (the previous pass's flush has read it)
         __syncthreads();
-        if (use_tile) for (int i = tid; i < 64 * TS; i += T) tile[i] = 0.f;
+        if (use_tile) for (int i = tid; i < step * TS; i += T) tile[i] = 0.f;  // (the whole pass's rows: 128 of them in a two-rows-per-lane pass)
         __syncthreads();
       }
       if (nbp <= 32 && use_tile && !staged) {
