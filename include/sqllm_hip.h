@@ -89,9 +89,10 @@ int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream);
  * device memory, 16-byte aligned, contents irrelevant before and after; sqllm_workspace_bytes(ops, n)
  * says how much the op (n = 1) or the group can use (0: none -- batch 1, batch tiles).  It serves one
  * launch at a time: launches on one stream may share it, concurrent streams may not.  What lives in it:
- *   2..16 rows (fused small launch)  vec transposed, xT[k][rows rounded up to 2 / 4 / 8 / 16]: the CSR walk of
- *            the dense workgroups then reads one cache line per non-zero instead of one per non-zero and
- *            row (one small kernel in front of the launch; only with a CSR term);
+ *   mfma_min_batch..16 rows (fused small launch, only with sparse terms)  vec transposed, xT[k][rows rounded up to 8 / 16]: the
+ *            CSR walk of the dense workgroups and the top-X slabs then read one cache line per k for all batch rows
+ *            instead of one per row; behind it vec as three bf16 planes in fragment order ((K / 32 + 1) x 3 KB): the
+ *            dense term loads its operands already split (one small kernel in front of the launch writes both);
  *   17+ rows  what sqllm_launch takes from stream-ordered scratch: vec transposed, its bf16 planes, the
  *            wide form's slabs.
  * A NULL or too small workspace is not an error: 2..16 rows then gather from vec itself (no allocation
@@ -338,6 +339,8 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *   "small_reserve_topx" 0 (default): with a transposed vec at hand the dense ranges of that launch are always planned for the
  *                     slots the (8-24) top-X workgroups leave; 1 does the same without one (one workgroup per top-X slab:
  *                     measured slower, profiles/r05_small_split_reserve.txt)
+ *   "small_planes"    1 (default): with a transposed vec at hand the fused small launch also takes vec split into bf16 planes
+ *                     (written by the same kernel in front); 0: its dense term splits vec in registers
  *   "validate_csr"    debugging aid, default 0.  1 = before every launch that carries a CSR term,
  *                     check ON THE DEVICE that rows[] is non-decreasing with rows[0] == 0 and
  *                     rows[N] == nnz, and return SQLLM_E_SPARSE otherwise.  Blocks the host (one

@@ -430,6 +430,7 @@ int sqllm_set_option(const char* name, int value) {
   if (!strcmp(name, "scratch_pool_threshold")) { knobs().scratch_pool_threshold.store(value ? 1 : 0); return SQLLM_OK; }
   if (!strcmp(name, "small_wgs_per_cu")) { knobs().small_wgs_per_cu.store(value); return SQLLM_OK; }
   if (!strcmp(name, "small_reserve_topx")) { knobs().small_reserve_topx.store(value ? 1 : 0); return SQLLM_OK; }
+  if (!strcmp(name, "small_planes")) { knobs().small_planes.store(value ? 1 : 0); return SQLLM_OK; }
   if (g_experimental.set_option) return g_experimental.set_option(name, value);  // (measurement library)
   return SQLLM_E_OPTION;
 }
@@ -455,6 +456,7 @@ int sqllm_get_option(const char* name, int* value) {
   if (!strcmp(name, "scratch_pool_threshold")) { *value = knobs().scratch_pool_threshold.load(); return SQLLM_OK; }
   if (!strcmp(name, "small_wgs_per_cu")) { *value = knobs().small_wgs_per_cu.load(); return SQLLM_OK; }
   if (!strcmp(name, "small_reserve_topx")) { *value = knobs().small_reserve_topx.load(); return SQLLM_OK; }
+  if (!strcmp(name, "small_planes")) { *value = knobs().small_planes.load(); return SQLLM_OK; }
   if (g_experimental.get_option) return g_experimental.get_option(name, value);  // (measurement library)
   return SQLLM_E_OPTION;
 }
@@ -672,7 +674,10 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     for (int i = 0; i < n; ++i) any_sparse = any_sparse || (ops[i].nnz > 0 && ops[i].rows) || (ops[i].full_rows && ops[i].topX > 0);
     const bool want_xT = any_sparse && ops[0].batch > 0 && ops[0].K > 0 && ops[0].vec && (reinterpret_cast<uintptr_t>(ops[0].vec) & 15u) == 0 &&
                          knobs().sparse_transpose.load(std::memory_order_relaxed);  // (the transposition reads vec 16 bytes at a time)
-    const int64_t xt_bytes = want_xT ? sqllm::transpose_small_bytes(ops[0].batch, ops[0].K) : 0;
+    // (vec transposed for the sparse terms, then its bf16 planes for the dense term: sqllm_prepare_small writes both)
+    const int64_t xt_only = want_xT ? sqllm::transpose_small_bytes(ops[0].batch, ops[0].K) : 0;
+    const bool want_planes = want_xT && knobs().small_planes.load(std::memory_order_relaxed);
+    const int64_t xt_bytes = xt_only + (want_planes ? sqllm::small_planes_bytes(ops[0].K) : 0);
     float* xT = nullptr;
     struct Scratch {  // the workspace-less names: stream-ordered scratch, as for the wider batches (never inside a capture:
       void* p = nullptr;  // its memory nodes cost more than the gathers -- profiles/r04_small_batch_layer.txt)
@@ -714,11 +719,14 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
     if (with_xT) {
       if (knobs().sparse_transpose.load(std::memory_order_relaxed) != 2) {  // (2: TIMING EXPERIMENT ONLY -- the kernel reads whatever the workspace holds)
-        const hipError_t e = sqllm::transpose_small(ops[0].vec, xT, ops[0].batch, ops[0].K, static_cast<hipStream_t>(stream), e0);
+        const hipError_t e = want_planes
+                                 ? sqllm::prepare_small(ops[0].vec, xT, reinterpret_cast<char*>(xT) + xt_only, ops[0].batch, ops[0].K, static_cast<hipStream_t>(stream), e0)
+                                 : sqllm::transpose_small(ops[0].vec, xT, ops[0].batch, ops[0].K, static_cast<hipStream_t>(stream), e0);
         if (e != hipSuccess) return static_cast<int>(e);
         a.ev_start = nullptr;
       }
       a.xT = xT;
+      if (want_planes) a.planes = reinterpret_cast<char*>(xT) + xt_only;
     }
     if (g_experimental.decorate) g_experimental.decorate(&a);  // (measurement library: timeline buffer)
     return static_cast<int>(sqllm::launch_small_split(ops[0].bits, a, static_cast<hipStream_t>(stream)));
@@ -919,7 +927,8 @@ int64_t sqllm_workspace_bytes(const sqllm_op* ops, int32_t n_ops) {
   if (takes_small_split(&ops[0])) {
     bool any_sparse = false;
     for (int i = 0; i < n_ops; ++i) any_sparse = any_sparse || (ops[i].nnz > 0 && ops[i].rows) || (ops[i].full_rows && ops[i].topX > 0);
-    if (any_sparse && knobs().sparse_transpose.load(std::memory_order_relaxed)) need = sqllm::transpose_small_bytes(ops[0].batch, ops[0].K);
+    if (any_sparse && knobs().sparse_transpose.load(std::memory_order_relaxed))
+      need = sqllm::transpose_small_bytes(ops[0].batch, ops[0].K) + (knobs().small_planes.load(std::memory_order_relaxed) ? sqllm::small_planes_bytes(ops[0].K) : 0);
   } else if (takes_mfma_path(&ops[0])) {
     need = (int64_t)WideScratch::layout(ops, n_ops, false).total();
   }

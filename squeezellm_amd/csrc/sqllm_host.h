@@ -37,6 +37,7 @@ struct Knobs {
   std::atomic<int> mfma_fuse_sparse{1};  // 17 rows up to the wide form: the op's CSR / top-X workgroups in the dense launch's grid (0: a launch of their own first)
   std::atomic<int> mfma_fuse_small{1};  // ... and up to 16 rows: the group's ops with their sparse terms as ONE launch of that kernel
   std::atomic<int> small_reserve_topx{0};  // fused small launch: 1 = plan the dense ranges for the slots the top-X slabs leave (measured: the coarser ranges cost more than the late starters, profiles/r05_small_split_reserve.txt)
+  std::atomic<int> small_planes{1};  // fused small launch with a transposed vec: its dense term loads vec already split into bf16 planes (written by the same kernel in front) instead of splitting in registers
   std::atomic<int> small_wgs_per_cu{0};  // fused small launch of the split kernel: dense workgroups per CU its planner aims at (0 = default)
 };
 constexpr int kMaxDevices = 32;

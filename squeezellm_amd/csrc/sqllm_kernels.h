@@ -175,6 +175,9 @@ hipError_t launch_small_split(int bits, const LaunchArgs& a, hipStream_t stream)
 hipError_t transpose_vec(const float* x, float* xT, int batch, int K, int Bp, hipStream_t stream, hipEvent_t ev_start);
 // 2..16 rows: xT[k][rp], rp = the batch rounded up to a power of two (K * rp floats)
 hipError_t transpose_small(const float* x, float* xT, int batch, int K, hipStream_t stream, hipEvent_t ev_start);
+// ... + vec as three bf16 planes in fragment order, row block 0 (K / 32 + 1 k blocks of 3 KB; planes 16-byte aligned behind xT)
+hipError_t prepare_small(const float* x, float* xT, void* planes, int batch, int K, hipStream_t stream, hipEvent_t ev_start);
+inline int64_t small_planes_bytes(int K) { return (int64_t)(K / 32 + 1) * 3072; }
 inline int64_t transpose_small_bytes(int batch, int K) { return (int64_t)K * (batch <= 2 ? 2 : batch <= 4 ? 4 : batch <= 8 ? 8 : 16) * 4; }
 hipError_t launch_batched_sparse(const LaunchArgs& a, hipStream_t stream);
 hipError_t check_csr(const int* rows, int N, int nnz, hipStream_t stream, int* bad);

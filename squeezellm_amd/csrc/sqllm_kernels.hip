@@ -2,6 +2,7 @@
 // sqllm_fused.h), the wide-batch matrix-core kernel, the small-batch column-lane kernel, the wide-batch sparse
 // launch, the vec transpose and the CSR check.
 #include "sqllm_fused.h"
+#include "sqllm_split_common.h"
 
 namespace sqllm {
 
@@ -803,6 +804,48 @@ __global__ void __launch_bounds__(256) sqllm_transpose_small(const float* __rest
   dst[rp] = v.y;
   dst[2 * rp] = v.z;
   dst[3 * rp] = v.w;
+}
+
+// The same in front of the fused small launch when it also takes vec ALREADY SPLIT: besides xT, vec as three bf16 planes
+// in fragment order (the layout of sqllm_split_vec, row block 0 only: chunk ((kb * 3 + plane) * 64 + lane) * 16 bytes,
+// lane = 16 * ((k / 8) % 4) + row, kb = k / 32; k block K / 32 all zero -- the address of lanes past a K range).  The
+// dense role then loads its A fragments ready-made: the split in registers was 54 of the 152 vector instructions of a
+// phase (2048 weights) of its loop.  A thread = (batch row, eight consecutive k's): two 16-byte loads, three 16-byte
+// stores that a wave lays down as 1 KB runs, eight 4-byte stores into xT (whole lines per wave).
+__global__ void __launch_bounds__(256) sqllm_prepare_small(const float* __restrict__ x, float* __restrict__ xT, u32x4* __restrict__ planes,
+                                                           int batch, int K, int lr) {
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  const unsigned b = t & 15u;
+  const unsigned k8 = t >> 4;  // group of eight k's
+  const unsigned k = 8u * k8;
+  if (k >= (unsigned)K + 32u) return;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (k < (unsigned)K && b < (unsigned)batch) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)b * K + k), c = *reinterpret_cast<const f32x4*>(x + (size_t)b * K + k + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+  }
+  uint32_t h[4], m[4], l[4];
+  split8(v, h, m, l);
+  u32x4* dst = planes + ((size_t)(k8 >> 2) * 3u * 64u + 16u * (k8 & 3u) + b);
+  dst[0] = u32x4{h[0], h[1], h[2], h[3]};
+  dst[64] = u32x4{m[0], m[1], m[2], m[3]};
+  dst[128] = u32x4{l[0], l[1], l[2], l[3]};
+  const unsigned rp = 1u << lr;
+  if (xT && k < (unsigned)K && b < rp) {
+    float* d = xT + ((size_t)k << lr) + b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[(size_t)j << lr] = v[j];
+  }
+}
+
+hipError_t prepare_small(const float* x, float* xT, void* planes, int batch, int K, hipStream_t stream, hipEvent_t ev_start) {
+  const int lr = batch <= 2 ? 1 : batch <= 4 ? 2 : batch <= 8 ? 3 : 4;
+  const unsigned threads = (unsigned)(K / 8 + 4) * 16u;
+  const dim3 grid((threads + 255u) / 256u);
+  u32x4* pl = static_cast<u32x4*>(planes);
+  if (ev_start) hipExtLaunchKernelGGL(sqllm_prepare_small, grid, dim3(256), 0, stream, ev_start, nullptr, 0, x, xT, pl, batch, K, lr);
+  else hipLaunchKernelGGL(sqllm_prepare_small, grid, dim3(256), 0, stream, x, xT, pl, batch, K, lr);
+  return hipGetLastError();
 }
 
 hipError_t transpose_small(const float* x, float* xT, int batch, int K, hipStream_t stream, hipEvent_t ev_start) {

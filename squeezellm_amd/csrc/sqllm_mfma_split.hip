@@ -55,18 +55,20 @@ namespace {
 // non-zero and batch row) with next to no arithmetic, and beside the dense loop it costs that wave's issue slots only.
 // So that nobody waits for the walker, the groups of a piece are handed out through an LDS ticket (the first seven
 // statically): when it is done it draws tickets like everybody else.
-template <int BITS, int MB, int WAVES, bool FOLD = false>
+// XMODE 0: vec as fp32 rows, split in registers; 3: vec ALREADY SPLIT into three bf16 planes in fragment order (`planes`:
+// sqllm_prepare_small, row block 0 -- MB == 1 only), the A fragments are loaded ready-made.
+template <int BITS, int MB, int WAVES, bool FOLD = false, int XMODE = 0>
 __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ x, const u32x4* __restrict__ q,
                                                       float* __restrict__ y, const float* __restrict__ lut, int K, int N,
                                                       int batch, int m0, int bid, int n_col_tiles, int units_total,
                                                       int units_per_wg, int units_stride, float* lds,
                                                       const int* __restrict__ csr_rows = nullptr, const int* __restrict__ csr_cols = nullptr,
                                                       const float* __restrict__ csr_vals = nullptr, const float* __restrict__ xT = nullptr,
-                                                      unsigned long long* tl = nullptr) {
+                                                      unsigned long long* tl = nullptr, const char* __restrict__ planes = nullptr) {
   static_assert(!FOLD || MB == 1, "the folded CSR walk serves one block of 16 rows");
+  static_assert(XMODE == 0 || MB == 1, "planes of row block 0 only");
   static_assert(!FOLD || WAVES * 16 * 64 >= 2 * kFoldStage, "the walk stages columns and values in the slab area");
-  constexpr int XMODE = 0;  // vec = fp32 rows, split in registers
-  constexpr int NX = 2 * MB;  // 16-byte registers of one phase's vec values
+  constexpr int NX = XMODE == 0 ? 2 * MB : XMODE * MB;  // 16-byte registers of one phase's vec values
   using F = Fmt<BITS>;
   constexpr int L = F::kLut, R = F::kRows, KU = F::kK;
   constexpr int NPH = KU / 8;  // phases of 8 k's per unit (4-bit: 1, 3-bit: 4)
@@ -150,12 +152,23 @@ __device__ __forceinline__ void dense_role_mfma_split(const float* __restrict__ 
     for (int r = 0; r < R; ++r) dw[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(qbase + (off + r * row_bytes)));
   };
   auto load_x = [&](int g, int ph, u32x4 (&dx)[NX]) {
-    const int u = clamp_unit(group_unit(g));
+    const int gu = group_unit(g);
+    const int u = clamp_unit(gu);
+    if constexpr (XMODE == 0) {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const float* p = x + xrow[mb] + u * KU + 8 * ph;
-      dx[2 * mb] = *reinterpret_cast<const u32x4*>(p);
-      dx[2 * mb + 1] = *reinterpret_cast<const u32x4*>(p + 4);
+      for (int mb = 0; mb < MB; ++mb) {
+        const float* p = x + xrow[mb] + u * KU + 8 * ph;
+        dx[2 * mb] = *reinterpret_cast<const u32x4*>(p);
+        dx[2 * mb + 1] = *reinterpret_cast<const u32x4*>(p + 4);
+      }
+    } else {
+      // fragment order (see dense_role_mfma_wide): 4-bit -- the group's 32 k's are ONE k block, lane for lane; 3-bit -- a
+      // lane row's unit is a k block of its own, phase ph = its quarter; past the K range: the zero k block
+      const uint32_t kb = (gu < u_end && gu >= u_beg) ? (BITS == 4 ? (uint32_t)u >> 2 : (uint32_t)u) : (uint32_t)K / 32u;
+      const uint32_t lp = BITS == 4 ? (uint32_t)lane : (uint32_t)(16 * ph + i16);
+      const uint32_t off = 3072u * kb + 16u * lp;
+#pragma unroll
+      for (int pl = 0; pl < XMODE; ++pl) dx[pl] = *reinterpret_cast<const u32x4*>(planes + off + 1024 * pl);
     }
   };
   u32x4 wa[R], wb[R];
@@ -366,9 +379,10 @@ sqllm_fused_batched_split_all(const float* x, const GroupArgs ga, const float* x
 // ------------------------------------------------------------------------------------------------
 constexpr int kSmallRows = 16;
 
-template <int BITS, int WAVES>
+// XM 3: vec comes already split into bf16 planes (`planes`, written with xT by sqllm_prepare_small); 0: fp32 rows.
+template <int BITS, int WAVES, int XM>
 __global__ void __launch_bounds__(WAVES * 64, 4)
-sqllm_fused_small_split(const float* x, const GroupArgs ga, const float* xT) {
+sqllm_fused_small_split(const float* x, const GroupArgs ga, const float* xT, const char* planes) {
   constexpr int T = WAVES * 64;
   __shared__ __attribute__((aligned(16))) float lds[cmax(split_lds_floats(BITS, WAVES) + kFoldSum + kFoldRp, kTopxLds)];
   // one round of scalar loads for the block table and segment 0 (see sqllm_fused_matvec)
@@ -389,10 +403,10 @@ sqllm_fused_small_split(const float* x, const GroupArgs ga, const float* xT) {
   const int bid = blockIdx.x - base;
   const int d = bid - gm.dense_block0;
   if (d >= 0 && d < gm.dense_blocks) {
-    dense_role_mfma_split<BITS, 1, WAVES, true>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, gm.batch, 0, d, gm.col_tiles,
+    dense_role_mfma_split<BITS, 1, WAVES, true, XM>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, gm.batch, 0, d, gm.col_tiles,
                                                 gm.units_total, gm.units_per_wg,
                                                 gm.dense_blocks == gm.col_tiles * gm.k_slices ? gm.k_slices * gm.units_per_wg : gm.units_total, lds,
-                                                gm.nnz > 0 ? sg.rows : nullptr, sg.cols, sg.vals, xT, SQLLM_PROBE_PTR(sg));
+                                                gm.nnz > 0 ? sg.rows : nullptr, sg.cols, sg.vals, xT, SQLLM_PROBE_PTR(sg), planes);
   } else if (bid < gm.topx_blocks) {
     // top-X slabs: gm.topx_blocks workgroups share the op's ceil(K / kTopxRows) slabs (with the transposed vec: 8-16
     // workgroups of several slabs each, all batch rows at once; without: one slab each, passes of 8 rows)
@@ -456,20 +470,24 @@ hipError_t launch_split_bits(const LaunchArgs& a, hipStream_t stream) {
 }  // namespace
 
 // 1..kMaxSegments ops over one vec (a.ga), up to kSmallRows rows: all three terms of every op in one launch
-hipError_t launch_small_split(int bits, const LaunchArgs& a, hipStream_t stream) {
-  if (a.ga.seg[0].gm.batch > kSmallRows) return hipErrorInvalidValue;
+namespace {
+template <int BITS, int XM>
+hipError_t launch_small_split_inst(const LaunchArgs& a, hipStream_t stream) {
   dim3 grid(a.ga.block0[a.ga.n_seg]);
   const float* x = static_cast<const float*>(a.x);
-  if (bits == 4) {
-    auto kern = sqllm_fused_small_split<4, kWaves>;
-    if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga, a.xT);
-    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga, a.xT);
-  } else {
-    auto kern = sqllm_fused_small_split<3, kWaves>;
-    if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga, a.xT);
-    else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga, a.xT);
-  }
+  const char* planes = static_cast<const char*>(a.planes);
+  auto kern = sqllm_fused_small_split<BITS, kWaves, XM>;
+  if (a.ev_start || a.ev_stop) hipExtLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, a.ev_start, a.ev_stop, 0, x, a.ga, a.xT, planes);
+  else hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), 0, stream, x, a.ga, a.xT, planes);
   return hipGetLastError();
+}
+}  // namespace
+
+// (a.planes: vec as bf16 planes of row block 0, or null: fp32 rows split in registers)
+hipError_t launch_small_split(int bits, const LaunchArgs& a, hipStream_t stream) {
+  if (a.ga.seg[0].gm.batch > kSmallRows) return hipErrorInvalidValue;
+  if (bits == 4) return a.planes ? launch_small_split_inst<4, 3>(a, stream) : launch_small_split_inst<4, 0>(a, stream);
+  return a.planes ? launch_small_split_inst<3, 3>(a, stream) : launch_small_split_inst<3, 0>(a, stream);
 }
 
 // one op (a.ga.seg[0]) in the tile form with its CSR / top-X workgroups in the same grid (a.xT: transposed vec or null)

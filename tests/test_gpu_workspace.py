@@ -102,11 +102,12 @@ def test_ws_launches_allocate_nothing_and_leave_the_pool_alone():
 def test_workspace_sizes():
     from squeezellm_amd import _lib
 
-    # batch 1 and the batch tiles need none; 5..16 rows the transposed vec (rows rounded up to 8 / 16); wider what the
-    # stream-ordered scratch would hold
+    # batch 1 and the batch tiles need none; 5..16 rows the transposed vec (rows rounded up to 8 / 16) and its bf16 planes in
+    # fragment order (K / 32 + 1 k blocks of 3 KB); wider what the stream-ordered scratch would hold
+    planes = (5120 // 32 + 1) * 3072
     assert _lib.workspace_bytes(4, 5120, 13824, 1, nnz=330_000, topX=10) == 0
     assert _lib.workspace_bytes(4, 5120, 13824, 4, nnz=330_000, topX=10) == 0
-    assert _lib.workspace_bytes(4, 5120, 13824, 8, nnz=330_000, topX=10) == 5120 * 8 * 4
-    assert _lib.workspace_bytes(4, 5120, 13824, 16, nnz=330_000, topX=10, n_ops=2) == 5120 * 16 * 4
+    assert _lib.workspace_bytes(4, 5120, 13824, 8, nnz=330_000, topX=10) == 5120 * 8 * 4 + planes
+    assert _lib.workspace_bytes(4, 5120, 13824, 16, nnz=330_000, topX=10, n_ops=2) == 5120 * 16 * 4 + planes
     assert _lib.workspace_bytes(4, 5120, 13824, 16) == 0  # dense-only: nothing to transpose for
     assert _lib.workspace_bytes(4, 5120, 13824, 64, nnz=330_000, topX=10) >= 5120 * 64 * 4

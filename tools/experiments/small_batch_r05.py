@@ -21,7 +21,7 @@ import torch
 import bench
 from squeezellm_amd import _lib, decode
 
-DEFAULTS = dict(mfma_split=1, mfma_fuse_small=1, mfma_fuse_sparse=1, cols_groups=1, sparse_transpose=1)
+DEFAULTS = dict(mfma_split=1, mfma_fuse_small=1, mfma_fuse_sparse=1, cols_groups=1, sparse_transpose=1, small_planes=1)
 
 
 def main():

@@ -206,5 +206,15 @@ s20)
   (echo -n "$v "; SQLLM_LIB=$L timeout 200 python bench.py --config $c --no-cpu-baseline --no-sub-records 2>/dev/null | grep "^{") >> gpurun_out/r05_s20_batch1_ab.txt; done; done; done
   cat gpurun_out/r05_s20.txt; wc -l gpurun_out/r05_s20_batch1_ab.txt
   ;;
-*) echo "usage: $0 s1..s20"; exit 2;;
+s23)
+  # round 5, session 23: vec already split into bf16 planes for the dense term of the fused small launch (written by the kernel in front, with xT)
+  mkdir -p gpurun_out
+  (timeout 600 python -m pytest tests/test_gpu_batched.py tests/test_gpu_decoder_layer.py tests/test_gpu_nonfinite.py tests/test_gpu_workspace.py tests/test_gpu_parity.py -m gpu -q 2>&1 | tail -3) > gpurun_out/r05_s23.txt
+  E=tools/experiments/small_batch_r05.py
+  (timeout 300 python $E --rows 5,8,12,16 --sets "default;small_planes=0" 2>&1 | grep '^{') >> gpurun_out/r05_s23.txt
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libr04.so timeout 300 python $E --rows 5,8,12,16 2>&1 | grep '^{') >> gpurun_out/r05_s23.txt
+  (timeout 300 python $E --bits 3 --rows 9,16 --sets "default;small_planes=0" 2>&1 | grep '^{') >> gpurun_out/r05_s23.txt
+  cat gpurun_out/r05_s23.txt
+  ;;
+*) echo "usage: $0 s1..s23"; exit 2;;
 esac
