@@ -221,6 +221,31 @@ def test_wide_form_at_13b_size_agrees_with_the_batch1_operator(qc, gpu, bits, ve
     assert H.rel_err(y[idx].cpu().numpy(), ref) <= TOL_FP64
 
 
+@pytest.mark.parametrize("vec", ["fp32", "fp16-born", "one-fp32-value"])
+@pytest.mark.parametrize("bits,K,N", [(4, 1024, 132), (3, 1024, 776), (4, 5120, 320)])
+@pytest.mark.parametrize("batch", [5, 9, 16])
+def test_fused_small_launch_with_planes(qc, gpu, bits, K, N, batch, vec):
+    """The fused small launch with a workspace loads vec already split into bf16 planes (written with the transposed copy by the
+    kernel in front): full-precision vec, fp16-born vec (all lo parts zero) and a mix, at 5 / 9 / 16 rows, incl. K = 5120 (161 k
+    blocks) -- against the oracle.  (A five-product path for fp16-born vec, switched by a flag from that kernel, was built on this
+    test and measured slower than six products: profiles/r05_small_planes_five_products.txt.)"""
+    import torch
+
+    case = H.make_case(bits, K, N, sparse=0.02, topX=3, heavy_rows=1, seed=bits * 7 + batch)
+    rng = np.random.default_rng(batch + K)
+    x = rng.normal(size=(batch, K)).astype(np.float32)
+    if vec != "fp32":
+        x = x.astype(np.float16).astype(np.float32)
+    if vec == "one-fp32-value":
+        x[batch - 1, K - 3] = np.float32(0.123456789)
+    mul = rng.normal(0, 0.5, size=(batch, N)).astype(np.float32)
+    t = H.to_torch(case, gpu)
+    yt = torch.from_numpy(mul.copy()).to(gpu)
+    H.call_op(qc, t, torch.from_numpy(x).to(gpu), yt, "hybrid", True)
+    torch.cuda.synchronize()
+    assert H.rel_err(yt.cpu().numpy(), H.oracle_ref(case, x, mul, "hybrid")) <= TOL_FP64
+
+
 def _routing(mfma_min, cols_min, cols_max):
     from squeezellm_amd import _lib
 

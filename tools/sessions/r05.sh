@@ -216,5 +216,17 @@ s23)
   (timeout 300 python $E --bits 3 --rows 9,16 --sets "default;small_planes=0" 2>&1 | grep '^{') >> gpurun_out/r05_s23.txt
   cat gpurun_out/r05_s23.txt
   ;;
-*) echo "usage: $0 s1..s23"; exit 2;;
+s24)
+  # round 5, session 24: five partial products for fp16-born vec on the fused small launch (flag from the kernel in front)
+  mkdir -p gpurun_out
+  (timeout 600 python -m pytest tests/test_gpu_batched.py tests/test_gpu_decoder_layer.py tests/test_gpu_nonfinite.py tests/test_gpu_workspace.py -m gpu -q 2>&1 | tail -3) > gpurun_out/r05_s24.txt
+  E=tools/experiments/small_batch_r05.py
+  (timeout 300 python $E --rows 5,8,12,16 --sets "default;small_planes=0" 2>&1 | grep '^{') >> gpurun_out/r05_s24.txt
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libplanes6.so timeout 300 python $E --rows 5,8,12,16 2>&1 | grep '^{') >> gpurun_out/r05_s24.txt
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libr04.so timeout 300 python $E --rows 5,8,12,16 2>&1 | grep '^{') >> gpurun_out/r05_s24.txt
+  (timeout 300 python $E --bits 3 --rows 9,16 2>&1 | grep '^{') >> gpurun_out/r05_s24.txt
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libplanes6.so timeout 300 python $E --bits 3 --rows 9,16 2>&1 | grep '^{') >> gpurun_out/r05_s24.txt
+  cat gpurun_out/r05_s24.txt
+  ;;
+*) echo "usage: $0 s1..s24"; exit 2;;
 esac
