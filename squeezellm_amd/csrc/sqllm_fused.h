@@ -511,7 +511,7 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
                         LIN ? &sg : nullptr, gm.sparse_last >> 1, nullptr, 0, LIN ? nullptr : SQLLM_PROBE_PTR(sg));
   } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
     // (never taken when the plan folds the top-X rows into the dense tiles)
-    topx_role<T, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, b0, nb, sp - gm.csr_blocks, lds);
+    topx_role<T, XT, AT, false, NoGate, BT>(x, reinterpret_cast<AT*>(sg.y), sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, b0, nb, sp - gm.csr_blocks, lds);  // (all BT rows of the pass in one go)
   }
 }
 

@@ -386,7 +386,7 @@ sqllm_sparse_batched(const float* x, const GroupArgs ga, const float* xT, int Bp
   } else if (sp < gm.csr_blocks + gm.topx_blocks) {
     for (int bb = 0; bb < rows_here; bb += 64) {
       if (bb) __syncthreads();
-      topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, m0 + bb, rows_here - bb < 64 ? rows_here - bb : 64,
+      topx_role<T, float, float, false, NoGate, 8>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, m0 + bb, rows_here - bb < 64 ? rows_here - bb : 64,
                                  sp - gm.csr_blocks, lds);
     }
   }
@@ -686,7 +686,7 @@ sqllm_fused_cols(const float* x, const GroupArgs ga) {
   } else if (sp >= 0 && sp < gm.csr_blocks) {
     csr_role<T, BT, float, float>(x, sg.y, sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds, nullptr, 0);
   } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
-    topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, b0, nb, sp - gm.csr_blocks, lds);
+    topx_role<T, float, float, false, NoGate, (BT < 4 ? BT : 4)>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, b0, nb, sp - gm.csr_blocks, lds);  // (passes of up to 4 rows: the kernel's 80 registers)
   }
 }
 

@@ -361,7 +361,7 @@ sqllm_fused_batched_split_all(const float* x, const GroupArgs ga, const float* x
       }
     }
   } else if (bid < gm.csr_blocks + gm.topx_blocks) {
-    topx_role<T, float, float>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, m0, rows_here, bid - gm.csr_blocks, lds);
+    topx_role<T, float, float, false, NoGate, 4>(x, sg.y, sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, m0, rows_here, bid - gm.csr_blocks, lds);  // (passes of 4 rows)
   }
 }
 

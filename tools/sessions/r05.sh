@@ -228,5 +228,16 @@ s24)
   (SQLLM_LIB=$PWD/squeezellm_amd/ab/libplanes6.so timeout 300 python $E --bits 3 --rows 9,16 2>&1 | grep '^{') >> gpurun_out/r05_s24.txt
   cat gpurun_out/r05_s24.txt
   ;;
-*) echo "usage: $0 s1..s24"; exit 2;;
+s25)
+  # round 5, session 25: the top-X role in passes of several batch rows in every batched kernel (libplanes6.so = the tree before)
+  mkdir -p gpurun_out
+  (timeout 600 python -m pytest tests/test_gpu_batched.py tests/test_gpu_decoder_layer.py tests/test_gpu_parity.py tests/test_gpu_property.py -m gpu -q 2>&1 | tail -3) > gpurun_out/r05_s25.txt
+  E=tools/experiments/small_batch_r05.py
+  for rep in 1 2; do
+  (timeout 300 python $E --rows 2,3,4,17,32,64 2>&1 | grep '^{') >> gpurun_out/r05_s25.txt
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libplanes6.so timeout 300 python $E --rows 2,3,4,17,32,64 2>&1 | grep '^{') >> gpurun_out/r05_s25.txt
+  done
+  cat gpurun_out/r05_s25.txt
+  ;;
+*) echo "usage: $0 s1..s25"; exit 2;;
 esac
