@@ -246,6 +246,34 @@ def test_fused_small_launch_with_planes(qc, gpu, bits, K, N, batch, vec):
     assert H.rel_err(yt.cpu().numpy(), H.oracle_ref(case, x, mul, "hybrid")) <= TOL_FP64
 
 
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("batch", [5, 8, 16])
+def test_fused_small_launch_sparse_edge_cases(qc, gpu, bits, batch):
+    """The edge cases of tests/test_gpu_parity.py::test_sparse_edge_cases on the fused small launch, whose dense workgroups
+    walk the CSR rows of their own tile (csr_tile_fold_staged): an empty CSR, empty rows at both ends and in the middle beside
+    rows that hold most of the non-zeros, duplicate top-X indices, one tile's share larger than a staging pass (4096 non-zeros:
+    several passes), a matrix with more rows than non-zeros (most tiles' shares empty), and accumulation into a non-zero mul."""
+    K, N = 512, 256
+    case = H.make_case(bits, K, N, seed=3)  # (a) nnz == 0 with the CSR operands present
+    case.update(rows=np.zeros(N + 1, np.int32), cols=np.zeros(0, np.int32), vals=np.zeros(0, np.float32))
+    x, mul, got = run_batched(qc, gpu, case, "spmv", batch)
+    assert H.rel_err(got, H.oracle_ref(case, x, mul, "spmv")) <= TOL_FP64
+    case = H.make_case(bits, K, N, sparse=0.01, heavy_rows=2, empty_rows=(0, 1, 100, N - 1), seed=4)  # (b)
+    for kind in ("spmv", "hybrid") if case.get("full_rows") is not None else ("spmv",):
+        x, mul, got = run_batched(qc, gpu, case, kind, batch)
+        assert H.rel_err(got, H.oracle_ref(case, x, mul, kind)) <= TOL_FP64
+    case = H.make_case(bits, K, N, sparse=0.01, topX=4, dup_topx=True, seed=5)  # (c) duplicate full_row_indices accumulate
+    x, mul, got = run_batched(qc, gpu, case, "hybrid", batch)
+    assert H.rel_err(got, H.oracle_ref(case, x, mul, "hybrid")) <= TOL_FP64
+    case = H.make_case(bits, 4096, 128, sparse=0.05, heavy_rows=3, seed=6)  # (d) ~26 k non-zeros in two tiles: several staging passes each
+    assert case["vals"].size > 2 * 2 * 4096
+    x, mul, got = run_batched(qc, gpu, case, "spmv", batch)
+    assert H.rel_err(got, H.oracle_ref(case, x, mul, "spmv")) <= TOL_FP64
+    case = H.make_case(bits, 128, 8192, sparse=0.0008, topX=2, seed=8)  # (e) ~840 non-zeros over 128 tiles
+    x, mul, got = run_batched(qc, gpu, case, "hybrid", batch)
+    assert H.rel_err(got, H.oracle_ref(case, x, mul, "hybrid")) <= TOL_FP64
+
+
 def _routing(mfma_min, cols_min, cols_max):
     from squeezellm_amd import _lib
 
