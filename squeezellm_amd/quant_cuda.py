@@ -100,7 +100,7 @@ def _persist(t, dtype, name: str):
 # allocated on a stream alive for the work already enqueued there.)
 _workspaces = {}
 _ws_need = {}
-_op = None
+_tls = __import__("threading").local()  # one sqllm_op descriptor per Python thread (ctypes releases the GIL during the call)
 
 
 def _workspace(dev: int, stream: int, need: int):
@@ -112,13 +112,12 @@ def _workspace(dev: int, stream: int, need: int):
 
 def _launch_ws(dev: int, bits, batch, K, width, pv, pq, pm, pl, csr=None, topx=None):
     """A batched op through sqllm_launch_ws with this module's workspace of (device, current stream)."""
-    global _op
     import ctypes
 
     lib = _lib.load()
-    if _op is None:
-        _op = _lib.SqllmOp()
-    o = _op
+    o = getattr(_tls, "op", None)
+    if o is None:
+        o = _tls.op = _lib.SqllmOp()
     o.bits, o.batch, o.K, o.N = bits, batch, K, width
     o.vec, o.qweight, o.mul, o.lookup_table = pv, pq, pm, pl
     o.rows, o.cols, o.vals, o.nnz = csr if csr is not None else (None, None, None, 0)
