@@ -239,5 +239,18 @@ s25)
   done
   cat gpurun_out/r05_s25.txt
   ;;
-*) echo "usage: $0 s1..s25"; exit 2;;
+s26)
+  # round 5, session 26: packed words of TWO groups ahead in the fused small launch's dense loop (libpf2.so: a variant build, described in LABNOTES.md round 5 item 4c; not kept in the tree)
+  mkdir -p gpurun_out
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libpf2.so timeout 600 python -m pytest tests/test_gpu_batched.py tests/test_gpu_nonfinite.py -m gpu -q 2>&1 | tail -3) > gpurun_out/r05_s26.txt
+  E=tools/experiments/small_batch_r05.py
+  for rep in 1 2; do
+  (timeout 300 python $E --rows 5,8,12,16 2>&1 | grep '^{') >> gpurun_out/r05_s26.txt
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libpf2.so timeout 300 python $E --rows 5,8,12,16 2>&1 | grep '^{') >> gpurun_out/r05_s26.txt
+  done
+  (timeout 300 python $E --dense-only --rows 8,16 2>&1 | grep '^{') >> gpurun_out/r05_s26.txt
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libpf2.so timeout 300 python $E --dense-only --rows 8,16 2>&1 | grep '^{') >> gpurun_out/r05_s26.txt
+  cat gpurun_out/r05_s26.txt
+  ;;
+*) echo "usage: $0 s1..s26"; exit 2;;
 esac
