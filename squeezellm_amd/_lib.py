@@ -137,8 +137,13 @@ def check(code: int, what: str) -> None:
         raise kind(f"{what}: {error_string(code)} (code {code})")
 
 
+option_epoch = 0  # bumped by every set_option: sizes cached on the Python side (quant_cuda's workspace needs) are per epoch
+
+
 def set_option(name: str, value: int) -> None:
+    global option_epoch
     check(load().sqllm_set_option(name.encode(), int(value)), f"sqllm_set_option({name})")
+    option_epoch += 1
 
 
 def get_option(name: str) -> int:

@@ -126,6 +126,9 @@ def _launch_ws(dev: int, bits, batch, K, width, pv, pq, pm, pl, csr=None, topx=N
     if prev != dev:
         _set_device(dev)
     try:
+        if _ws_need.get("epoch") != _lib.option_epoch:  # a library option changed: the routes (and what they can use) may have
+            _ws_need.clear()
+            _ws_need["epoch"] = _lib.option_epoch
         key = (dev, bits, batch, K, width, csr is not None and csr[3] > 0, topx is not None and topx[2] > 0)
         need = _ws_need.get(key)
         if need is None:
