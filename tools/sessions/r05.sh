@@ -252,5 +252,43 @@ s26)
   (SQLLM_LIB=$PWD/squeezellm_amd/ab/libpf2.so timeout 300 python $E --dense-only --rows 8,16 2>&1 | grep '^{') >> gpurun_out/r05_s26.txt
   cat gpurun_out/r05_s26.txt
   ;;
-*) echo "usage: $0 s1..s26"; exit 2;;
+s27)
+  # round 5, session 27: where the waves of the 16-row launches wait (s_waitcnt / barrier vs issue stalls), s45 and dense-only
+  R=$PWD; mkdir -p gpurun_out; cd /tmp; export TMPDIR=/tmp
+  for v in s45 s0; do
+    extra=""; [ $v = s0 ] && extra="--dense-only"
+    rm -rf /tmp/prof_w_$v
+    timeout 400 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d /tmp/prof_w_$v -o x -- python $R/tools/experiments/small_batch_r05.py --rows 16 --no-breakdown $extra > /tmp/prof_w_$v.log 2>&1
+    python $R/tools/rocprof_summary.py "$(find /tmp/prof_w_$v -name '*.db' | head -1)" --by-grid --match sqllm --top 12 > $R/gpurun_out/r05_s27_waits_$v.txt
+  done
+  cd $R; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+  tail -40 gpurun_out/r05_s27_waits_s45.txt
+  ;;
+s28)
+  # round 5, session 28: the next column's lookups issued between the six matrix instructions of a column (libpipe.so = -DSQLLM_SMALL_PIPE)
+  mkdir -p gpurun_out
+  L=${2:-pipe}
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$L.so timeout 600 python -m pytest tests/test_gpu_batched.py tests/test_gpu_nonfinite.py -m gpu -q 2>&1 | tail -3) > gpurun_out/r05_s28_$L.txt
+  E=tools/experiments/small_batch_r05.py
+  for rep in 1 2; do
+  (timeout 300 python $E --rows 5,8,12,16 2>&1 | grep '^{') >> gpurun_out/r05_s28_$L.txt
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$L.so timeout 300 python $E --rows 5,8,12,16 2>&1 | grep '^{') >> gpurun_out/r05_s28_$L.txt
+  done
+  (timeout 300 python $E --bits 3 --rows 9,16 2>&1 | grep '^{') >> gpurun_out/r05_s28_$L.txt
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$L.so timeout 300 python $E --bits 3 --rows 9,16 2>&1 | grep '^{') >> gpurun_out/r05_s28_$L.txt
+  cat gpurun_out/r05_s28_$L.txt
+  ;;
+s29)
+  # round 5, session 29: what the 16-row launch costs without its matrix instructions (abl1), without its LDS lookups (abl2), with the
+  # weight loads (abl3) / the vec plane loads (abl4) folded onto eight groups per wave -- variant libraries with WRONG results, timing only
+  mkdir -p gpurun_out
+  E=tools/experiments/small_batch_r05.py
+  for L in ${2:-HEAD abl1 abl2 abl3 abl4 HEAD}; do
+    X=""; [ $L != HEAD ] && X=$PWD/squeezellm_amd/ab/lib$L.so
+    (SQLLM_LIB=$X timeout 300 python $E --rows 16 2>&1 | grep '^{') >> gpurun_out/r05_s29.txt
+    (SQLLM_LIB=$X timeout 300 python $E --rows 16 --dense-only 2>&1 | grep '^{') >> gpurun_out/r05_s29.txt
+  done
+  cat gpurun_out/r05_s29.txt
+  ;;
+*) echo "usage: $0 s1..s29"; exit 2;;
 esac
