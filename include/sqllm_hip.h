@@ -17,11 +17,13 @@
  *   - qweight is int32 [height, width] = [K/32*bits, N]; lookup_table is [N, 2^bits];
  *   - the callee retains nothing and never synchronises; it enqueues its kernels on `stream` (NULL = the
  *     legacy default stream, which is what the reference used; the Python binding passes torch's current
- *     stream so calls are graph-capturable): exactly ONE kernel and no allocation for batch 1 and for
- *     batches up to 16 rows; the `_ws` entry points (sqllm_launch_ws ...) allocate nothing at ANY batch --
- *     what a wider batch needs beside its operands comes out of the caller's workspace, as the reference's
- *     launchers allocate nothing (quant_cuda_kernel.cu:580-657); the workspace-less names fall back to
- *     stream-ordered scratch there (see sqllm_launch);
+ *     stream so calls are graph-capturable): exactly ONE kernel and no allocation for batch 1 and the batch
+ *     tiles (up to mfma_min_batch - 1 rows, and every dense-only op up to 16 rows); the `_ws` entry points
+ *     (sqllm_launch_ws ...) with a workspace of sqllm_workspace_bytes allocate nothing at ANY batch -- what a
+ *     batch needs beside its operands comes out of the caller's workspace, as the reference's launchers
+ *     allocate nothing (quant_cuda_kernel.cu:580-657) -- and with a NULL workspace nothing up to 16 rows;
+ *     the workspace-less names (sqllm_launch, sqllm_launch_group(s), the reference operator names) take
+ *     stream-ordered scratch instead wherever a workspace would have been used (see sqllm_launch);
  *   - return value: 0 on success, a negative SQLLM_E_* code for rejected arguments (the reference
  *     validated nothing and read out of bounds instead), or a positive hipError_t from the launch.
  *
@@ -76,11 +78,15 @@ typedef struct sqllm_op {
 } sqllm_op;
 
 /* Enqueue  mul += W_lut . vec (+ CSR . vec) (+ full_rows^T . vec scattered)  on `stream`: one fused
- * kernel up to 16 rows.  A wider batch is up to four kernels -- a transpose of vec into stream-ordered
- * scratch (hipMallocAsync / hipFreeAsync on `stream`; only with a CSR term), the sparse terms, (wide
- * form only: "mfma_wide_min_batch") the split of vec into bf16 planes, again in such scratch, and
- * the dense term on the matrix cores.  Inside a stream capture the scratch becomes memory nodes of
- * the graph unless option "scratch_in_capture" is 0.  No host synchronisation in either case.
+ * kernel up to 16 rows -- from mfma_min_batch rows on, an op WITH sparse terms gets a small kernel in
+ * front of it that writes vec transposed (and split into bf16 planes) into stream-ordered scratch
+ * (hipMallocAsync / hipFreeAsync on `stream`; never inside a stream capture: the sparse terms gather
+ * from vec itself there).  A wider batch is up to four kernels -- a transpose of vec into such scratch
+ * (only with a CSR term), the sparse terms, (wide form only: "mfma_wide_min_batch") the split of vec
+ * into bf16 planes, again in such scratch, and the dense term on the matrix cores; inside a stream
+ * capture that scratch becomes memory nodes of the graph unless option "scratch_in_capture" is 0.
+ * No host synchronisation in any case.  On first use of the scratch per device the release threshold of
+ * the device's default memory pool is raised (option "scratch_pool_threshold").
  * Callers that own a workspace use sqllm_launch_ws instead: nothing is allocated then. */
 int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream);
 
@@ -95,9 +101,9 @@ int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream);
  *            dense term loads its operands already split (one small kernel in front of the launch writes both);
  *   17+ rows  what sqllm_launch takes from stream-ordered scratch: vec transposed, its bf16 planes, the
  *            wide form's slabs.
- * A NULL or too small workspace is not an error: 2..16 rows then gather from vec itself (no allocation
- * either), 17+ rows fall back to the stream-ordered scratch of sqllm_launch.  A stream capture of a `_ws`
- * launch with a sufficient workspace contains kernel nodes only. */
+ * A NULL or too small workspace is not an error: 2..16 rows then gather from vec itself (ONE kernel, no
+ * allocation, the default memory pool untouched), 17+ rows fall back to the stream-ordered scratch of
+ * sqllm_launch.  A stream capture of a `_ws` launch with a sufficient workspace contains kernel nodes only. */
 int64_t sqllm_workspace_bytes(const sqllm_op* ops, int32_t n_ops);
 int sqllm_launch_ws(const sqllm_op* op, void* workspace, int64_t workspace_bytes, sqllm_stream_t stream);
 
@@ -347,7 +353,9 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     tiny kernel, a 4-byte read-back, a stream synchronise; 4 bytes of stream-ordered
  *                     scratch on the current device per check); skipped while the stream is capturing.
  *                     Meant for the fused linear, which counts on `rows` to detect completion.
- * Returns SQLLM_E_OPTION for an unknown name. */
+ * Returns SQLLM_E_OPTION for an unknown name and for a value outside the option's range: switches take 0 / 1 only,
+ * "small_wgs_per_cu" 0..8, "cu_count" up to 65536, "target_wgs" / "groups_per_wave" up to 2^24, the *_min_batch /
+ * *_max_batch thresholds any non-negative int.  No value of any option changes a result beyond fp32 round-off. */
 int sqllm_set_option(const char* name, int value);
 int sqllm_get_option(const char* name, int* value);
 

@@ -27,7 +27,7 @@ SOURCES = ["sqllm_kernels.hip", "sqllm_mfma_split.hip", "sqllm_mfma_wide.hip", "
 EXPERIMENTAL = os.path.join(CSRC, "experimental")
 EXPERIMENT_SOURCES = ["experimental/sqllm_ablation.hip", "experimental/sqllm_stream.hip", "experimental/sqllm_pair.hip",
                       "experimental/sqllm_pass.hip", "experimental/sqllm_experimental.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("sqllm_kernels.h", "sqllm_decode.h", "sqllm_roles.h", "sqllm_fused.h", "sqllm_split_common.h", "sqllm_host.h")] + [os.path.join(INCLUDE, "sqllm_hip.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("sqllm_kernels.h", "sqllm_decode.h", "sqllm_roles.h", "sqllm_fused.h", "sqllm_split_common.h", "sqllm_host.h", "sqllm_probe.h")] + [os.path.join(INCLUDE, "sqllm_hip.h")]
 EXPERIMENT_HEADERS = [os.path.join(EXPERIMENTAL, h) for h in ("sqllm_pass.h", "sqllm_pass_api.h")]
 ARCH = "gfx950"
 # -amdgpu-kernarg-preload-count: the kernels' leading explicit arguments (the vec pointer) arrive in SGPRs instead of

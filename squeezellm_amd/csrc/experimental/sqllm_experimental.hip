@@ -36,6 +36,7 @@ struct ExpKnobs {
   std::atomic<int> pass_poll_sleep{4};     // gated pass: s_sleep(2) units between two polls of a gate
   std::atomic<int> pass_timeout_ms{2000};  // ... a gate that stays shut this long ends the launch with status 1
   std::atomic<int> pass_wgs_per_cu{0};     // ... workgroups per CU the kernel is launched with (0 = the occupancy query's answer)
+  std::atomic<int> skip_prepare_small{0};  // TIMING ONLY: the fused small launch without sqllm_prepare_small / sqllm_transpose_small in front (garbage results)
 };
 ExpKnobs g_xknobs[kMaxDevices];
 ExpKnobs& xknobs() { return g_xknobs[device_slot()]; }
@@ -204,6 +205,7 @@ void decorate(sqllm::LaunchArgs* a) {
 }
 
 int csr_ablation_bits() { return xknobs().ablate_csr.load(std::memory_order_relaxed); }
+bool skip_prepare_small() { return xknobs().skip_prepare_small.load(std::memory_order_relaxed) != 0; }
 
 int set_option(const char* name, int value) {
   if (!strcmp(name, "stream")) { xknobs().stream.store(value > 1 ? -1 : value); return SQLLM_OK; }  // 0 off, 1 on, 2 default (off)
@@ -215,6 +217,7 @@ int set_option(const char* name, int value) {
   if (!strcmp(name, "pass_poll_sleep")) { xknobs().pass_poll_sleep.store(value); return SQLLM_OK; }
   if (!strcmp(name, "pass_timeout_ms")) { xknobs().pass_timeout_ms.store(value > 0 ? value : 1); return SQLLM_OK; }
   if (!strcmp(name, "pass_wgs_per_cu")) { xknobs().pass_wgs_per_cu.store(value); return SQLLM_OK; }
+  if (!strcmp(name, "skip_prepare_small")) { xknobs().skip_prepare_small.store(value ? 1 : 0); return SQLLM_OK; }
   return SQLLM_E_OPTION;
 }
 
@@ -228,6 +231,7 @@ int get_option(const char* name, int* value) {
   if (!strcmp(name, "pass_poll_sleep")) { *value = xknobs().pass_poll_sleep.load(); return SQLLM_OK; }
   if (!strcmp(name, "pass_timeout_ms")) { *value = xknobs().pass_timeout_ms.load(); return SQLLM_OK; }
   if (!strcmp(name, "pass_wgs_per_cu")) { *value = xknobs().pass_wgs_per_cu.load(); return SQLLM_OK; }
+  if (!strcmp(name, "skip_prepare_small")) { *value = xknobs().skip_prepare_small.load(); return SQLLM_OK; }
   return SQLLM_E_OPTION;
 }
 
@@ -238,6 +242,7 @@ struct InstallHooks {
     g_experimental.route = route;
     g_experimental.decorate = decorate;
     g_experimental.csr_ablation_bits = csr_ablation_bits;
+    g_experimental.skip_prepare_small = skip_prepare_small;
   }
 } g_install_hooks;
 

@@ -409,28 +409,41 @@ const char* sqllm_error_string(int code) {
   return "unknown sqllm error";
 }
 
+// Every option value is range-checked: switches take 0 / 1 only, counts their documented range (include/sqllm_hip.h).
+// (Until round 5 any non-negative value was stored as it came, and one of them -- sparse_transpose = 2 -- switched to a
+// timing-only mode that left the kernels reading an unwritten workspace; that experiment now lives behind the measurement
+// library's hook, ExperimentalHooks::skip_prepare_small.)
 int sqllm_set_option(const char* name, int value) {
   if (!name || value < 0) return SQLLM_E_OPTION;
-  if (!strcmp(name, "target_wgs")) { knobs().target_wgs.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "groups_per_wave")) { knobs().groups_per_wave.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "sparse_last")) { knobs().sparse_last.store(value ? 1 : 0); return SQLLM_OK; }
-  if (!strcmp(name, "cols_groups")) { knobs().cols_groups.store(value ? 1 : 0); return SQLLM_OK; }
-  if (!strcmp(name, "cu_count")) { knobs().cu_count.store(value); return SQLLM_OK; }  // for GPU-less planning tests
-  if (!strcmp(name, "mfma_min_batch")) { knobs().mfma_min_batch.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "cols_min_batch")) { knobs().cols_min_batch.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "cols_max_batch")) { knobs().cols_max_batch.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "sparse_transpose")) { knobs().sparse_transpose.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "scratch_in_capture")) { knobs().scratch_in_capture.store(value ? 1 : 0); return SQLLM_OK; }
-  if (!strcmp(name, "validate_csr")) { knobs().validate_csr.store(value ? 1 : 0); return SQLLM_OK; }
-  if (!strcmp(name, "mfma_split")) { knobs().mfma_split.store(value ? 1 : 0); return SQLLM_OK; }
-  if (!strcmp(name, "split_planes_min_batch")) { knobs().split_planes_min_batch.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "mfma_wide_min_batch")) { knobs().mfma_wide_min_batch.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "mfma_fuse_small")) { knobs().mfma_fuse_small.store(value ? 1 : 0); return SQLLM_OK; }
-  if (!strcmp(name, "mfma_fuse_sparse")) { knobs().mfma_fuse_sparse.store(value ? 1 : 0); return SQLLM_OK; }
-  if (!strcmp(name, "scratch_pool_threshold")) { knobs().scratch_pool_threshold.store(value ? 1 : 0); return SQLLM_OK; }
-  if (!strcmp(name, "small_wgs_per_cu")) { knobs().small_wgs_per_cu.store(value); return SQLLM_OK; }
-  if (!strcmp(name, "small_reserve_topx")) { knobs().small_reserve_topx.store(value ? 1 : 0); return SQLLM_OK; }
-  if (!strcmp(name, "small_planes")) { knobs().small_planes.store(value ? 1 : 0); return SQLLM_OK; }
+  struct Opt { const char* name; std::atomic<int> Knobs::*field; int max; };
+  static const Opt kOptions[] = {
+      {"target_wgs", &Knobs::target_wgs, 1 << 24},
+      {"groups_per_wave", &Knobs::groups_per_wave, 1 << 24},
+      {"cu_count", &Knobs::cu_count, 1 << 16},  // for GPU-less planning tests
+      {"sparse_last", &Knobs::sparse_last, 1},
+      {"cols_groups", &Knobs::cols_groups, 1},
+      {"mfma_min_batch", &Knobs::mfma_min_batch, 0x7fffffff},  // (a huge value: never)
+      {"cols_min_batch", &Knobs::cols_min_batch, 0x7fffffff},
+      {"cols_max_batch", &Knobs::cols_max_batch, 0x7fffffff},
+      {"sparse_transpose", &Knobs::sparse_transpose, 1},
+      {"scratch_in_capture", &Knobs::scratch_in_capture, 1},
+      {"validate_csr", &Knobs::validate_csr, 1},
+      {"mfma_split", &Knobs::mfma_split, 1},
+      {"split_planes_min_batch", &Knobs::split_planes_min_batch, 0x7fffffff},
+      {"mfma_wide_min_batch", &Knobs::mfma_wide_min_batch, 0x7fffffff},
+      {"mfma_fuse_small", &Knobs::mfma_fuse_small, 1},
+      {"mfma_fuse_sparse", &Knobs::mfma_fuse_sparse, 1},
+      {"scratch_pool_threshold", &Knobs::scratch_pool_threshold, 1},
+      {"small_wgs_per_cu", &Knobs::small_wgs_per_cu, 8},
+      {"small_reserve_topx", &Knobs::small_reserve_topx, 1},
+      {"small_planes", &Knobs::small_planes, 1},
+  };
+  for (const Opt& o : kOptions)
+    if (!strcmp(name, o.name)) {
+      if (value > o.max) return SQLLM_E_OPTION;
+      (knobs().*(o.field)).store(value);
+      return SQLLM_OK;
+    }
   if (g_experimental.set_option) return g_experimental.set_option(name, value);  // (measurement library)
   return SQLLM_E_OPTION;
 }
@@ -615,8 +628,10 @@ struct WideScratch {
 // One kernel over 1..kMaxSegments ops that share vec, K, bits and batch.  `lin` (optional) points at
 // the fused-linear descriptors the ops were taken from: `ops` is then lin[i].op.
 // `ws` / `ws_bytes`: the caller's workspace (sqllm_launch_*_ws; sqllm_workspace_bytes says how much a group can use), or null.
+// `ws_entry`: the call came through a `_ws` entry point -- up to 16 rows nothing is allocated then, workspace or not.
 static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t stream, hipEvent_t e0,
-                                    hipEvent_t e1, const sqllm_linear* lin = nullptr, void* ws = nullptr, int64_t ws_bytes = 0) {
+                                    hipEvent_t e1, const sqllm_linear* lin = nullptr, void* ws = nullptr, int64_t ws_bytes = 0,
+                                    bool ws_entry = false) {
   if (n < 1 || n > sqllm::kMaxSegments) return SQLLM_E_GROUP;
   if (!ops && !lin) return SQLLM_E_NULL;
   // (small batches: a group whose summed columns pass the column-lane kernel's test takes that kernel as ONE launch --
@@ -679,14 +694,15 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     const bool want_planes = want_xT && knobs().small_planes.load(std::memory_order_relaxed);
     const int64_t xt_bytes = xt_only + (want_planes ? sqllm::small_planes_bytes(ops[0].K) : 0);
     float* xT = nullptr;
-    struct Scratch {  // the workspace-less names: stream-ordered scratch, as for the wider batches (never inside a capture:
-      void* p = nullptr;  // its memory nodes cost more than the gathers -- profiles/r04_small_batch_layer.txt)
+    struct Scratch {  // the workspace-less names only: stream-ordered scratch, as for the wider batches (never inside a capture:
+      void* p = nullptr;  // its memory nodes cost more than the gathers -- profiles/r04_small_batch_layer.txt; never for a `_ws`
+                          // entry point: those allocate nothing up to 16 rows and leave the default pool alone -- the walk gathers)
       hipStream_t s = nullptr;
       ~Scratch() { if (p) (void)hipFreeAsync(p, s); }
     } own;
     if (want_xT && ws && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0 && ws_bytes >= xt_bytes) {
       xT = static_cast<float*>(ws);
-    } else if (want_xT) {
+    } else if (want_xT && !ws_entry) {
       own.s = static_cast<hipStream_t>(stream);
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
       if (hipStreamIsCapturing(own.s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
@@ -718,7 +734,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     }
     for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
     if (with_xT) {
-      if (knobs().sparse_transpose.load(std::memory_order_relaxed) != 2) {  // (2: TIMING EXPERIMENT ONLY -- the kernel reads whatever the workspace holds)
+      if (!(g_experimental.skip_prepare_small && g_experimental.skip_prepare_small())) {  // (measurement library only: what the kernel in front costs)
         const hipError_t e = want_planes
                                  ? sqllm::prepare_small(ops[0].vec, xT, reinterpret_cast<char*>(xT) + xt_only, ops[0].batch, ops[0].K, static_cast<hipStream_t>(stream), e0)
                                  : sqllm::transpose_small(ops[0].vec, xT, ops[0].batch, ops[0].K, static_cast<hipStream_t>(stream), e0);
@@ -936,11 +952,11 @@ int64_t sqllm_workspace_bytes(const sqllm_op* ops, int32_t n_ops) {
 }
 
 int sqllm_launch_ws(const sqllm_op* op, void* workspace, int64_t workspace_bytes, sqllm_stream_t stream) {
-  return launch_group_with_events(op, 1, stream, nullptr, nullptr, nullptr, workspace, workspace_bytes);
+  return launch_group_with_events(op, 1, stream, nullptr, nullptr, nullptr, workspace, workspace_bytes, true);
 }
 
 int sqllm_launch_group_ws(const sqllm_op* ops, int32_t n_ops, void* workspace, int64_t workspace_bytes, sqllm_stream_t stream) {
-  return launch_group_with_events(ops, n_ops, stream, nullptr, nullptr, nullptr, workspace, workspace_bytes);
+  return launch_group_with_events(ops, n_ops, stream, nullptr, nullptr, nullptr, workspace, workspace_bytes, true);
 }
 
 int sqllm_launch_groups_ws(const sqllm_op* ops, const int32_t* group_sizes, int32_t n_groups, void* workspace,
@@ -949,7 +965,7 @@ int sqllm_launch_groups_ws(const sqllm_op* ops, const int32_t* group_sizes, int3
   if (n_groups < 0 || (n_groups > 0 && (!ops || !group_sizes))) return SQLLM_E_NULL;
   int32_t at = 0;
   for (int32_t g = 0; g < n_groups; ++g) {
-    int rc = launch_group_with_events(ops + at, group_sizes[g], stream, nullptr, nullptr, nullptr, workspace, workspace_bytes);
+    int rc = launch_group_with_events(ops + at, group_sizes[g], stream, nullptr, nullptr, nullptr, workspace, workspace_bytes, true);
     if (rc != SQLLM_OK) return rc;
     at += group_sizes[g];
     if (n_done) *n_done = g + 1;

@@ -61,6 +61,9 @@ struct ExperimentalHooks {
   // last word on a product launch's arguments: ablation bits, unused-LDS pad, timeline buffer
   void (*decorate)(sqllm::LaunchArgs* a) = nullptr;
   int (*csr_ablation_bits)() = nullptr;  // ride along in KernelGeom::sparse_last (bits 1..)
+  // timing experiment: the fused small launch WITHOUT the kernel in front of it (it then reads whatever the workspace
+  // holds: results are garbage by design -- which is why the product library has no such mode)
+  bool (*skip_prepare_small)() = nullptr;
 };
 extern ExperimentalHooks g_experimental;
 

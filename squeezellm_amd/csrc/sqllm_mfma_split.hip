@@ -48,13 +48,14 @@ namespace sqllm {
 
 namespace {
 
-// FOLD: the op's CSR term is walked by these workgroups themselves (csr_tile_fold, sqllm_roles.h; MB == 1 only):
-// csr_rows / csr_cols / csr_vals are the op's CSR (csr_rows null: no such term), LDS grows by the sums, the tile's row
-// pointers and a ticket word.  ONE wave of the workgroup (the last) walks the piece's share of the tile's non-zeros
-// while the other seven decode: the walk is a chain of round trips (columns -> gathers of vec, one cache line per
-// non-zero and batch row) with next to no arithmetic, and beside the dense loop it costs that wave's issue slots only.
-// So that nobody waits for the walker, the groups of a piece are handed out through an LDS ticket (the first seven
-// statically): when it is done it draws tickets like everybody else.
+// FOLD: the op's CSR term is walked by these workgroups themselves (csr_tile_fold_staged, sqllm_roles.h; MB == 1 only):
+// csr_rows / csr_cols / csr_vals are the op's CSR (csr_rows null: no such term).  CSR rows are output channels, so the
+// non-zeros of the piece's 64-column tile are one contiguous range of cols / vals; the pieces of a tile cut it in proportion
+// to their K ranges.  ALL waves take part: the first columns / values of the piece's share and their row searches go out
+// before the dense loop and are STAGED in the slab area of LDS (idle until the epilogue), the walk itself runs after the
+// loop -- lane = (group, batch row), a group of 8 / 16 lanes takes a run of the share one non-zero per step, groups dealt
+// round-robin (static: no ticket) -- and its sums meet the dense partial sums in the tile's own epilogue.  (One wave
+// walking beside seven decoding, with groups by LDS ticket, was measured and dropped: profiles/r05_walker_wave.txt.)
 // XMODE 0: vec as fp32 rows, split in registers; 3: vec ALREADY SPLIT into three bf16 planes in fragment order (`planes`:
 // sqllm_prepare_small, row block 0 -- MB == 1 only), the A fragments are loaded ready-made.
 template <int BITS, int MB, int WAVES, bool FOLD = false, int XMODE = 0>

@@ -98,12 +98,20 @@ def _persist(t, dtype, name: str):
 # stream), grown on demand, and launches through sqllm_launch_ws: the library then allocates nothing and never touches
 # the default memory pool.  (A buffer is replaced, not freed early: torch's caching allocator keeps a block that was
 # allocated on a stream alive for the work already enqueued there.)
+# While the stream is CAPTURING the cached buffer is neither used nor grown: a graph bakes the raw address in, so the
+# buffer of a capture must live exactly as long as the graph does.  The workspace of a captured call is therefore a
+# temporary like any other tensor of the captured region -- torch's allocator takes it from the graph's private pool, which
+# keeps it for the graph's replays and orders its reuse inside the capture -- and is not remembered here (a remembered
+# one would be handed to the next graph captured on the same stream and dangle once the first graph is destroyed).
 _workspaces = {}
 _ws_need = {}
 _tls = __import__("threading").local()  # one sqllm_op descriptor per Python thread (ctypes releases the GIL during the call)
+_is_capturing = torch.cuda.is_current_stream_capturing
 
 
 def _workspace(dev: int, stream: int, need: int):
+    if _is_capturing():
+        return torch.empty(need, dtype=torch.uint8, device=torch.device("cuda", dev))
     ws = _workspaces.get((dev, stream))
     if ws is None or ws.numel() < need:
         ws = _workspaces[(dev, stream)] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=torch.device("cuda", dev))

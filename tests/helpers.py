@@ -80,8 +80,66 @@ def rel_err(got, ref):
     return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
 
 
-def call_op(qc, t, x, y, kind, batched):
-    """Dispatch to the quant_cuda name for (bits, kind, batched) with the reference argument order."""
+ENTRIES = ("module", "named", "ws-null")
+
+
+def _call_c_abi(t, x, y, kind, batched, entry):
+    """The same op straight through the C ABI (include/sqllm_hip.h), on torch's current stream:
+    "named"   -- the header's `sqllm_vecquant{3,4}matmul*` symbol for (bits, kind, batched): what a C / C++ caller binds in
+                 place of quant_cuda_kernel.cu:132-738; workspace-less, so wider batches take the library's stream-ordered
+                 scratch (or, inside a capture, memory nodes / the gathering fallback);
+    "ws-null" -- sqllm_launch_ws with a NULL workspace (the no-workspace contract of the `_ws` entry points)."""
+    import ctypes
+
+    import torch
+
+    from squeezellm_amd import _lib
+
+    lib = _lib.load()
+    b, K, N = t["bits"], t["K"], t["N"]
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    q, lut = t["qweight"], t["lookup_table"]
+    height = q.shape[0]
+    batch = x.shape[0] if batched else 0
+    assert x.dtype == torch.float32 and y.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous()
+    sparse = kind in ("spmv", "hybrid")
+    hybrid = kind == "hybrid"
+    nnz = t["vals"].numel() if sparse else 0
+    topX = t["full_rows"].shape[1] if hybrid else 0
+    with torch.cuda.device(x.device):
+        if entry == "ws-null":
+            op = _lib.SqllmOp(bits=b, batch=batch, K=K, N=N, vec=x.data_ptr(), qweight=q.data_ptr(), mul=y.data_ptr(), lookup_table=lut.data_ptr())
+            if sparse:
+                op.rows, op.cols, op.vals, op.nnz = t["rows"].data_ptr(), t["cols"].data_ptr(), t["vals"].data_ptr(), nnz
+            if hybrid:
+                op.full_rows, op.full_row_indices, op.topX = t["full_rows"].data_ptr(), t["full_row_indices"].data_ptr(), topX
+            rc = lib.sqllm_launch_ws(ctypes.byref(op), None, 0, stream)
+            what = "sqllm_launch_ws(NULL)"
+        else:
+            sfx = "_batched" if batched else ""
+            tail = (batch, K, stream) if batched else (stream,)
+            if kind == "dense":
+                what = f"sqllm_vecquant{b}matmul_nuq_perchannel{sfx}"
+                args = (x.data_ptr(), q.data_ptr(), y.data_ptr(), lut.data_ptr(), height, N)
+            elif kind == "spmv":
+                what = f"sqllm_vecquant{b}matmul_spmv_nuq_perchannel{sfx}"
+                args = (t["rows"].data_ptr(), t["cols"].data_ptr(), t["vals"].data_ptr(), x.data_ptr(), y.data_ptr(), N, q.data_ptr(), lut.data_ptr(),
+                        height, N, nnz)
+            elif kind == "hybrid":
+                what = f"sqllm_vecquant{b}matmul_spmv_hybrid_nuq_perchannel{sfx}"
+                args = (t["rows"].data_ptr(), t["cols"].data_ptr(), t["vals"].data_ptr(), x.data_ptr(), t["full_rows"].data_ptr(),
+                        t["full_row_indices"].data_ptr(), y.data_ptr(), N, q.data_ptr(), lut.data_ptr(), height, N, nnz, topX)
+            else:
+                raise ValueError(kind)
+            rc = getattr(lib, what)(*args, *tail)
+    _lib.check(rc, what)
+
+
+def call_op(qc, t, x, y, kind, batched, entry="module"):
+    """Dispatch to the quant_cuda name for (bits, kind, batched) with the reference argument order (entry "module"), or to
+    the C ABI directly ("named", "ws-null": see _call_c_abi)."""
+    if entry != "module":
+        return _call_c_abi(t, x, y, kind, batched, entry)
     b = t["bits"]
     sfx = "_batched" if batched else ""
     if kind == "dense":

@@ -302,6 +302,30 @@ def test_every_documented_option_round_trips():
         assert _lib.get_option(n) == before, n
 
 
+def test_option_values_are_range_checked():
+    """No option value switches the product library to anything but a documented route (`sparse_transpose = 2`
+    was stored as it came and made the fused small launch read an unwritten workspace): switches take 0 / 1 only, counts
+    their documented range, and a rejected value leaves the stored one untouched."""
+    from squeezellm_amd import _lib
+
+    lib = _lib.load()
+    switches = ["sparse_last", "cols_groups", "sparse_transpose", "scratch_in_capture", "validate_csr", "mfma_split", "mfma_fuse_small",
+                "mfma_fuse_sparse", "scratch_pool_threshold", "small_reserve_topx", "small_planes"]
+    for n in switches:
+        before = _lib.get_option(n)
+        for bad in (2, 3, 1 << 30, -1):
+            assert lib.sqllm_set_option(n.encode(), bad) == -7, (n, bad)  # SQLLM_E_OPTION
+        assert _lib.get_option(n) == before, n
+    for n, top in (("small_wgs_per_cu", 8), ("cu_count", 1 << 16), ("target_wgs", 1 << 24), ("groups_per_wave", 1 << 24)):
+        before = _lib.get_option(n)
+        assert lib.sqllm_set_option(n.encode(), top + 1) == -7 and lib.sqllm_set_option(n.encode(), -1) == -7, n
+        assert lib.sqllm_set_option(n.encode(), top) == 0
+        _lib.set_option(n, before)
+    for n in ("mfma_min_batch", "cols_min_batch", "cols_max_batch", "split_planes_min_batch", "mfma_wide_min_batch"):
+        assert lib.sqllm_set_option(n.encode(), 0x7fffffff) == 0 and lib.sqllm_set_option(n.encode(), -1) == -7, n
+        _lib.set_option(n, 0)
+
+
 def test_product_library_carries_no_measurement_variants():
     """The ablation kernel instantiations, timeline probes, calibration kernels and the measured-and-not-adopted
     kernels (streaming, column-pair tables) live in libsqllm_hip_ablation.so only; variant switches cannot be
@@ -408,5 +432,6 @@ def test_product_sources_carry_no_measurement_routing():
     assert "SQLLM_ABLATION_BUILD" not in src
     assert not any(os.path.basename(s) in ("sqllm_stream.hip", "sqllm_pair.hip", "sqllm_pass.hip") for s in B.SOURCES)
     lib = _lib.load()
-    for name in (b"stream", b"pair4", b"ablate", b"lds_pad", b"pass_poll_sleep"):
+    for name in (b"stream", b"pair4", b"ablate", b"lds_pad", b"pass_poll_sleep", b"skip_prepare_small"):
         assert lib.sqllm_set_option(name, 1) == -7, name  # SQLLM_E_OPTION
+    assert "TIMING" not in src and "skip_prepare_small()" in src  # the one timing-only mode sits behind a (null) hook

@@ -22,7 +22,7 @@ def qc():
     return quant_cuda
 
 
-def run_batched(qc, gpu, case, kind, batch, seed=1):
+def run_batched(qc, gpu, case, kind, batch, seed=1, entry="module"):
     import torch
 
     rng = np.random.default_rng(seed)
@@ -30,7 +30,7 @@ def run_batched(qc, gpu, case, kind, batch, seed=1):
     mul = rng.normal(0, 0.5, size=(batch, case["N"])).astype(np.float32)
     t = H.to_torch(case, gpu)
     yt = torch.from_numpy(mul).to(gpu)
-    H.call_op(qc, t, torch.from_numpy(x).to(gpu), yt, kind, True)
+    H.call_op(qc, t, torch.from_numpy(x).to(gpu), yt, kind, True, entry=entry)
     torch.cuda.synchronize()
     return x, mul, yt.cpu().numpy()
 
@@ -38,12 +38,14 @@ def run_batched(qc, gpu, case, kind, batch, seed=1):
 @pytest.mark.parametrize("bits,K,N", [(4, 256, 192), (3, 96 * 2, 260), (4, 1024, 132), (3, 1024, 776), (4, 32, 4), (3, 32, 8)])
 @pytest.mark.parametrize("kind", ["dense", "spmv", "hybrid"])
 @pytest.mark.parametrize("batch", [9, 16, 17, 33, 64, 65, 130])
-def test_wide_batches_vs_oracle(qc, gpu, bits, K, N, kind, batch):
-    """One, two and four row blocks of 16, several passes of 64 rows, ragged ends in every dimension
+@pytest.mark.parametrize("entry", H.ENTRIES)
+def test_wide_batches_vs_oracle(qc, gpu, bits, K, N, kind, batch, entry):
+    """Through the module (caller workspace), the header's named `*_batched` symbols and sqllm_launch_ws(NULL) (both: the
+    library's stream-ordered scratch).  One, two and four row blocks of 16, several passes of 64 rows, ragged ends in every dimension
     (N not a multiple of the 64-column tile, K = 32: a single unit, fewer units than lane rows)."""
     case = H.make_case(bits, K, N, sparse=0.03 if kind != "dense" else 0, topX=3 if kind == "hybrid" else 0,
                        heavy_rows=1 if kind != "dense" and N >= 8 else 0, seed=bits * 1000 + K + N)
-    x, mul, got = run_batched(qc, gpu, case, kind, batch)
+    x, mul, got = run_batched(qc, gpu, case, kind, batch, entry=entry)
     assert H.rel_err(got, H.oracle_ref(case, x, mul, kind)) <= TOL_FP64
 
 
@@ -153,12 +155,14 @@ def test_wide_form_whole_rounds(qc, gpu, bits, cus):
     assert H.rel_err(got, H.oracle_ref(case, x, mul, "dense")) <= TOL_FP64
 
 
-@pytest.mark.parametrize("scratch_in_capture", [1, 0])
-def test_wide_form_in_a_captured_graph(gpu, scratch_in_capture):
-    """A wide-form hybrid op captured into a graph and replayed twice.  With scratch_in_capture = 1 the graph carries the
-    group's scratch block as an allocation and a free node around the transpose / split / sparse / dense / reduce launches;
-    with 0 it is allocation-free: the CSR role gathers from vec, the wide form (forced here) splits vec in registers and
-    its K slices add atomically."""
+@pytest.mark.parametrize("mode", ["caller-workspace", "scratch-nodes", "no-scratch"])
+def test_wide_form_in_a_captured_graph(gpu, mode):
+    """A wide-form hybrid op captured into a graph and replayed twice.  "caller-workspace": the pass owns a workspace
+    (sqllm_launch_groups_ws) -- kernel nodes only; "scratch-nodes": the workspace-less entry point with scratch_in_capture = 1
+    -- the graph carries the group's scratch block as an allocation and a free node around the transpose / split / sparse /
+    dense / reduce launches (node types asserted in tests/test_gpu_workspace.py); "no-scratch": workspace-less with
+    scratch_in_capture = 0 -- allocation-free: the CSR role gathers from vec, the wide form (forced here) splits vec in
+    registers and its K slices add atomically."""
     import torch
 
     from squeezellm_amd import _lib, decode
@@ -173,8 +177,9 @@ def test_wide_form_in_a_captured_graph(gpu, scratch_in_capture):
     yt = y0.clone()
     try:
         _lib.set_option("mfma_wide_min_batch", 17)
-        _lib.set_option("scratch_in_capture", scratch_in_capture)
-        seq = decode.OpSequence([lay], [xt], [yt], batched=True)
+        _lib.set_option("scratch_in_capture", 0 if mode == "no-scratch" else 1)
+        seq = decode.OpSequence([lay], [xt], [yt], batched=True, workspace=mode == "caller-workspace")
+        assert (seq._ws is not None) == (mode == "caller-workspace")
         g = seq.graph(warmup=1)
         for _ in range(2):
             yt.copy_(y0)
@@ -403,11 +408,12 @@ LLAMA13B = [(5120, 5120), (5120, 13824), (13824, 5120)]
 @pytest.mark.parametrize("bits", [3, 4])
 @pytest.mark.parametrize("K,N", LLAMA13B)
 @pytest.mark.parametrize("batch", [2, 8, 16])
-def test_llama13b_shapes_batched_hybrid(qc, gpu, bits, K, N, batch):
-    """BASELINE config 4 at full size on all three 13B shapes, against the C oracle (batch 2 and 8: batch
-    tiles; 16: matrix cores)."""
+@pytest.mark.parametrize("entry", H.ENTRIES)
+def test_llama13b_shapes_batched_hybrid(qc, gpu, bits, K, N, batch, entry):
+    """BASELINE config 4 at full size on all three 13B shapes, against the C oracle (batch 2: batch tiles / column-lane
+    kernel; 8 and 16: the fused small launch at 4 bits, 16 only at 3), through all three entries."""
     case = H.make_case(bits, K, N, sparse=0.0045, topX=10, heavy_rows=10, seed=13)
-    x, mul, got = run_batched(qc, gpu, case, "hybrid", batch)
+    x, mul, got = run_batched(qc, gpu, case, "hybrid", batch, entry=entry)
     ref = H.c_matvec(H.c_oracle(), case, x, mul, batched=True)
     assert H.rel_err(got, ref) <= TOL_FP64
 
@@ -484,25 +490,27 @@ def test_wide_batch_sparse_term_transposed_or_gathered(qc, gpu, bits):
                 assert H.rel_err(y.cpu().numpy(), want) <= TOL_FP64, (B, flag)
         finally:
             _lib.set_option("sparse_transpose", 1)
-        # captured, with the scratch as graph memory nodes (default) and without (the role gathers)
+        # captured through the header's NAMED entry point (workspace-less), with the scratch as graph memory nodes (default)
+        # and without (the role gathers); and through the module, whose captured call takes its workspace as a temporary of
+        # the captured region (kernel nodes only)
         try:
-            for in_capture in (1, 0):
+            for entry, in_capture in (("named", 1), ("named", 0), ("module", 1)):
                 _lib.set_option("scratch_in_capture", in_capture)
                 y = torch.from_numpy(mul.copy()).to(gpu)
                 ystat = y.clone()
                 s = torch.cuda.Stream(device=gpu)
                 s.wait_stream(torch.cuda.current_stream(gpu))
                 with torch.cuda.stream(s):
-                    H.call_op(qc, t, xt, ystat.clone(), "hybrid", True)  # warm-up outside the capture
+                    H.call_op(qc, t, xt, ystat.clone(), "hybrid", True, entry=entry)  # warm-up outside the capture
                 torch.cuda.current_stream(gpu).wait_stream(s)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    H.call_op(qc, t, xt, ystat, "hybrid", True)
+                    H.call_op(qc, t, xt, ystat, "hybrid", True, entry=entry)
                 ystat.copy_(y)
                 g.replay()
                 g.replay()  # (the graph owns its scratch: replays must not interfere; mul accumulates twice)
                 torch.cuda.synchronize()
                 want2 = H.oracle_ref(case, x, want, "hybrid")
-                assert H.rel_err(ystat.cpu().numpy(), want2) <= TOL_FP64, (B, "graph", in_capture)
+                assert H.rel_err(ystat.cpu().numpy(), want2) <= TOL_FP64, (B, "graph", entry, in_capture)
         finally:
             _lib.set_option("scratch_in_capture", 1)

@@ -25,12 +25,12 @@ def qc():
     return quant_cuda
 
 
-def _run(qc, gpu, case, x, mul):
+def _run(qc, gpu, case, x, mul, entry="module"):
     import torch
 
     t = H.to_torch(case, gpu)
     yt = torch.from_numpy(mul.copy()).to(gpu)
-    H.call_op(qc, t, torch.from_numpy(x).to(gpu), yt, "hybrid", True)
+    H.call_op(qc, t, torch.from_numpy(x).to(gpu), yt, "hybrid", True, entry=entry)
     torch.cuda.synchronize()
     return yt.cpu().numpy()
 
@@ -48,15 +48,13 @@ def _same_pattern(got, ref):
 POISONS = ["vec+inf", "vec-inf", "vec-nan", "vec-both-infs", "codebook-inf", "codebook-nan", "vals-inf", "vals-nan"]
 
 
-@pytest.mark.parametrize("form", ["default", "wide"])
 @pytest.mark.parametrize("poison", POISONS)
-@pytest.mark.parametrize("batch", [5, 16, 64, 256])
+@pytest.mark.parametrize("form,batch", [("default", 5), ("default", 16), ("default", 64), ("default", 256), ("wide", 64), ("wide", 256)])
 @pytest.mark.parametrize("bits", [3, 4])
-def test_nonfinite_operands_follow_the_reference(qc, gpu, bits, batch, poison, form):
+@pytest.mark.parametrize("entry", H.ENTRIES)
+def test_nonfinite_operands_follow_the_reference(qc, gpu, bits, batch, poison, form, entry):
     from squeezellm_amd import _lib
 
-    if form == "wide" and batch < 64:
-        pytest.skip("the wide form starts at 64 rows")
     K, N = 512, 320
     case = H.make_case(bits, K, N, sparse=0.02, topX=3, heavy_rows=1, seed=10 * bits + batch)
     rng = np.random.default_rng(batch)
@@ -85,7 +83,7 @@ def test_nonfinite_operands_follow_the_reference(qc, gpu, bits, batch, poison, f
     try:
         if form == "wide":
             _lib.set_option("mfma_wide_min_batch", 64)
-        got = _run(qc, gpu, case, x, mul)
+        got = _run(qc, gpu, case, x, mul, entry)
     finally:
         _lib.set_option("mfma_wide_min_batch", 0)
     _same_pattern(got, ref)

@@ -25,7 +25,7 @@ def qc():
     return quant_cuda
 
 
-def run_op(qc, gpu, case, kind, batch, seed=1, mul_init="random"):
+def run_op(qc, gpu, case, kind, batch, seed=1, mul_init="random", entry="module"):
     import torch
 
     rng = np.random.default_rng(seed)
@@ -38,7 +38,7 @@ def run_op(qc, gpu, case, kind, batch, seed=1, mul_init="random"):
         mul = np.zeros((batch, N) if batched else (N,), np.float32)
     t = H.to_torch(case, gpu)
     xt, yt = torch.from_numpy(x).to(gpu), torch.from_numpy(mul).to(gpu)
-    H.call_op(qc, t, xt, yt, kind, batched)
+    H.call_op(qc, t, xt, yt, kind, batched, entry=entry)
     torch.cuda.synchronize()
     return x, mul, yt.cpu().numpy()
 
@@ -49,10 +49,13 @@ SMALL = [(4, 128, 128), (3, 128, 128), (4, 256, 384), (3, 96 * 2, 260), (4, 32, 
 @pytest.mark.parametrize("bits,K,N", SMALL)
 @pytest.mark.parametrize("kind", ["dense", "spmv", "hybrid"])
 @pytest.mark.parametrize("batch", [0, 1, 2, 3, 8, 9])
-def test_small_shapes_vs_oracle(qc, gpu, bits, K, N, kind, batch):
+@pytest.mark.parametrize("entry", H.ENTRIES)
+def test_small_shapes_vs_oracle(qc, gpu, bits, K, N, kind, batch, entry):
+    """Every op at every small batch through the Python module, through the header's NAMED C symbol for it (workspace-less) and
+    through sqllm_launch_ws with a NULL workspace (tests/helpers.py: _call_c_abi)."""
     case = H.make_case(bits, K, N, sparse=0.03 if kind != "dense" else 0, topX=3 if kind == "hybrid" else 0,
                        heavy_rows=1 if kind != "dense" and N >= 8 else 0, seed=bits * 1000 + K + N)
-    x, mul, got = run_op(qc, gpu, case, kind, batch)
+    x, mul, got = run_op(qc, gpu, case, kind, batch, entry=entry)
     ref = H.oracle_ref(case, x, mul, kind)
     assert got.shape == ref.shape
     assert H.rel_err(got, ref) <= TOL_FP64

@@ -3,8 +3,10 @@
 The reference's launchers allocate nothing (/root/reference/squeezellm/quant_cuda_kernel.cu:580-657).  With a workspace
 of sqllm_workspace_bytes the batched ops keep that contract at every batch: a stream capture of a 64- or 256-row hybrid
 op contains kernel nodes only (no memory-allocation / free nodes), and the default memory pool's release threshold is left
-as the application set it.  The workspace-less names keep their stream-ordered scratch as the fallback (and only they
-touch the pool).  Runs in a fresh process: the pool threshold is process-wide state other tests may have raised.
+as the application set it; with a NULL workspace nothing is allocated up to 16 rows either (the sparse terms gather).  The
+workspace-less names keep their stream-ordered scratch as the fallback (and only they touch the pool): checked against the
+oracle eagerly and as a captured graph with memory nodes, replayed twice.  Runs in a fresh process: the pool threshold is
+process-wide state other tests may have raised.
 """
 import os
 import subprocess
@@ -73,13 +75,56 @@ for batch in (8, 64, 256):
     out[f"node_types_{batch}"] = types
     hip.hipGraphDestroy(g)
 out["threshold_after_ws"] = threshold()
-# (c) the workspace-less name at 64 rows: stream-ordered scratch, the fallback -- it may raise the pool's threshold
+# (c) sqllm_launch_ws with a NULL workspace at 8 rows (fused small launch): no allocation either -- the sparse terms gather
+# from vec -- so the pool is still as it was, and the result is the oracle's
+case8 = H.make_case(4, 512, 320, sparse=0.02, topX=3, heavy_rows=1, seed=8)
+t8 = H.to_torch(case8, dev)
+x8 = np.random.default_rng(8).normal(size=(8, 512)).astype(np.float32)
+m8 = np.random.default_rng(9).normal(size=(8, 320)).astype(np.float32)
+y8 = torch.from_numpy(m8).to(dev)
+H.call_op(quant_cuda, t8, torch.from_numpy(x8).to(dev), y8, "hybrid", True, entry="ws-null")
+torch.cuda.synchronize()
+out["err_ws_null_8"] = float(H.rel_err(y8.cpu().numpy(), H.oracle_ref(case8, x8, m8, "hybrid")))
+out["threshold_after_ws_null"] = threshold()
+# (d) the workspace-less name at 64 rows: stream-ordered scratch, the fallback -- it may raise the pool's threshold
 op.batch = 64
-yt64 = torch.zeros(64, 320, device=dev)
-op.vec, op.mul = torch.randn(64, 512, device=dev).data_ptr(), yt64.data_ptr()
+x64 = np.random.default_rng(64).normal(size=(64, 512)).astype(np.float32)
+m64 = np.random.default_rng(65).normal(size=(64, 320)).astype(np.float32)
+xt64, yt64 = torch.from_numpy(x64).to(dev), torch.from_numpy(m64).to(dev)
+op.vec, op.mul = xt64.data_ptr(), yt64.data_ptr()
 assert lib.sqllm_launch(ctypes.byref(op), torch.cuda.current_stream().cuda_stream) == 0
 torch.cuda.synchronize()
 out["threshold_after_fallback"] = threshold()
+out["err_fallback_64"] = float(H.rel_err(yt64.cpu().numpy(), H.oracle_ref(case, x64, m64, "hybrid")))  # (`case`: the 256-row loop's last)
+# (e) the same workspace-less op CAPTURED with scratch_in_capture = 1 (default): the graph carries the scratch as a
+# memory-allocation and a memory-free node; instantiated and replayed twice it accumulates the oracle's result twice
+yt64.copy_(torch.from_numpy(m64))
+s = torch.cuda.Stream(dev)
+torch.cuda.synchronize()
+assert hip.hipStreamBeginCapture(ctypes.c_void_p(s.cuda_stream), 0) == 0
+rc = lib.sqllm_launch(ctypes.byref(op), s.cuda_stream)
+g = ctypes.c_void_p()
+assert hip.hipStreamEndCapture(ctypes.c_void_p(s.cuda_stream), ctypes.byref(g)) == 0 and rc == 0, rc
+n = ctypes.c_size_t(0)
+assert hip.hipGraphGetNodes(g, None, ctypes.byref(n)) == 0
+nodes = (ctypes.c_void_p * n.value)()
+assert hip.hipGraphGetNodes(g, nodes, ctypes.byref(n)) == 0
+types = []
+for nd in nodes:
+    ty = ctypes.c_int(-1)
+    assert hip.hipGraphNodeGetType(ctypes.c_void_p(nd), ctypes.byref(ty)) == 0
+    types.append(ty.value)
+out["node_types_scratch_capture"] = types
+ge = ctypes.c_void_p()
+assert hip.hipGraphInstantiate(ctypes.byref(ge), g, None, None, 0) == 0
+ref1 = H.oracle_ref(case, x64, m64, "hybrid")
+for rep in (1, 2):
+    assert hip.hipGraphLaunch(ge, ctypes.c_void_p(s.cuda_stream)) == 0
+    assert hip.hipStreamSynchronize(ctypes.c_void_p(s.cuda_stream)) == 0
+    want = ref1 if rep == 1 else H.oracle_ref(case, x64, ref1.astype(np.float32), "hybrid")
+    out[f"err_scratch_capture_replay{rep}"] = float(H.rel_err(yt64.cpu().numpy(), want))
+hip.hipGraphExecDestroy(ge)
+hip.hipGraphDestroy(g)
 print("RESULT " + json.dumps(out))
 """
 
@@ -96,7 +141,14 @@ def test_ws_launches_allocate_nothing_and_leave_the_pool_alone():
         types = out[f"node_types_{batch}"]
         assert types and all(t == 0 for t in types), (batch, types)  # hipGraphNodeTypeKernel only: no MemAlloc (10) / MemFree (11)
     assert out["threshold_after_ws"] == out["threshold_start"], out  # the default pool is left as it was
-    assert out["threshold_after_fallback"] >= out["threshold_after_ws"]
+    # a NULL workspace at 8 rows: still nothing allocated, and the gathered result is right
+    assert out["threshold_after_ws_null"] == out["threshold_start"] and out["err_ws_null_8"] <= 2e-5, out
+    # the workspace-less name: scratch from the pool (threshold raised), result checked against the oracle
+    assert out["threshold_after_fallback"] >= out["threshold_after_ws"] and out["err_fallback_64"] <= 2e-5, out
+    # ... and captured: MemAlloc (10) and MemFree (11) nodes around the kernels, two replays right
+    types = out["node_types_scratch_capture"]
+    assert 10 in types and 11 in types and types.count(0) >= 2, types
+    assert out["err_scratch_capture_replay1"] <= 2e-5 and out["err_scratch_capture_replay2"] <= 2e-5, out
 
 
 def test_workspace_sizes():

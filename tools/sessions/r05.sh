@@ -2,6 +2,8 @@
 # Round 5: every gpurun session of the round, replayable -- gpurun --timeout 1500 -- 'bash tools/sessions/r05.sh s15'
 # (run from the repo root; results land in gpurun_out/, the ones quoted in DESIGN.md / LABNOTES.md were copied to profiles/r05_*).
 # Variant libraries some sessions compare (squeezellm_amd/ab/lib*.so) are built by the recipes in LABNOTES.md, round 5.
+# (Round 6: the timing-only mode those sessions switched on as `sparse_transpose=2` left the product library; it is now
+# `skip_prepare_small=1` of the measurement library -- run those lines with SQLLM_LIB=squeezellm_amd/libsqllm_hip_ablation.so.)
 case "$1" in
 s1)
   # round 5, session 1: parity of the folded CSR walk + same-box A/B of the 13B s45 layer by rows (HEAD vs the round-4 build)
@@ -67,7 +69,7 @@ s6)
   # round 5, session 6: what the transposition launch costs (timing-only knob: the walk reads a stale transposed copy)
   mkdir -p gpurun_out
   E=tools/experiments/small_batch_r05.py
-  (timeout 300 python $E --rows 5,8,16 --sets "default;sparse_transpose=2" 2>&1 | grep '^{') > gpurun_out/r05_s6.txt
+  (timeout 300 python $E --rows 5,8,16 --sets "default;skip_prepare_small=1" 2>&1 | grep '^{') > gpurun_out/r05_s6.txt
   (timeout 300 python $E --rows 8,16 --dense-only 2>&1 | grep '^{') >> gpurun_out/r05_s6.txt
   cat gpurun_out/r05_s6.txt
   ;;
@@ -76,7 +78,7 @@ s7)
   mkdir -p gpurun_out
   (timeout 900 python -m pytest tests/test_gpu_batched.py tests/test_gpu_decoder_layer.py tests/test_gpu_parity.py tests/test_gpu_module.py -m gpu -q --maxfail=30 2>&1 | tail -15) > gpurun_out/r05_s7_tests.log
   E=tools/experiments/small_batch_r05.py
-  (timeout 300 python $E --rows 5,8,12,16 --sets "default;sparse_transpose=2" 2>&1 | grep '^{') > gpurun_out/r05_s7.txt
+  (timeout 300 python $E --rows 5,8,12,16 --sets "default;skip_prepare_small=1" 2>&1 | grep '^{') > gpurun_out/r05_s7.txt
   (timeout 300 python $E --rows 8,16 --no-ws 2>&1 | grep '^{') >> gpurun_out/r05_s7.txt
   (timeout 300 python $E --bits 3 --rows 5,8,16 --sets "default;mfma_min_batch=5" 2>&1 | grep '^{') >> gpurun_out/r05_s7.txt
   tail -3 gpurun_out/r05_s7_tests.log; cat gpurun_out/r05_s7.txt
@@ -93,7 +95,7 @@ s9)
   # round 5, session 9: one round of workgroups including the top-X slabs
   mkdir -p gpurun_out
   E=tools/experiments/small_batch_r05.py
-  (timeout 300 python $E --rows 5,8,12,16 --sets "default;sparse_transpose=2" 2>&1 | grep '^{') > gpurun_out/r05_s9.txt
+  (timeout 300 python $E --rows 5,8,12,16 --sets "default;skip_prepare_small=1" 2>&1 | grep '^{') > gpurun_out/r05_s9.txt
   (SQLLM_LIB=$PWD/squeezellm_amd/ab/libr04.so timeout 300 python $E --rows 5,8,12,16 2>&1 | grep '^{') >> gpurun_out/r05_s9.txt
   (timeout 300 python $E --rows 8,16 --dense-only 2>&1 | grep '^{') >> gpurun_out/r05_s9.txt
   (timeout 300 python $E --bits 3 --rows 8,16 --sets "default;mfma_min_batch=5" 2>&1 | grep '^{') >> gpurun_out/r05_s9.txt
@@ -104,7 +106,7 @@ s10)
   mkdir -p gpurun_out
   (timeout 900 python -m pytest tests/test_gpu_batched.py tests/test_gpu_decoder_layer.py tests/test_gpu_parity.py -m gpu -q --maxfail=30 2>&1 | tail -5) > gpurun_out/r05_s10_tests.log
   E=tools/experiments/small_batch_r05.py
-  (timeout 300 python $E --rows 5,8,12,16 --sets "default;sparse_transpose=2" 2>&1 | grep '^{') > gpurun_out/r05_s10.txt
+  (timeout 300 python $E --rows 5,8,12,16 --sets "default;skip_prepare_small=1" 2>&1 | grep '^{') > gpurun_out/r05_s10.txt
   (timeout 300 python $E --rows 8,16 --no-ws 2>&1 | grep '^{') >> gpurun_out/r05_s10.txt
   (timeout 300 python $E --bits 3 --rows 8,16 --sets "default;mfma_min_batch=5" 2>&1 | grep '^{') >> gpurun_out/r05_s10.txt
   (SQLLM_LIB=$PWD/squeezellm_amd/libsqllm_hip_ablation.so timeout 200 python tools/experiments/small_split_timeline.py --rows 16 2>&1 | grep -v amdgpu.ids) > gpurun_out/r05_s10_timeline.txt
@@ -115,7 +117,7 @@ s11)
   mkdir -p gpurun_out
   (timeout 900 python -m pytest tests/test_gpu_batched.py tests/test_gpu_decoder_layer.py tests/test_gpu_parity.py -m gpu -q --maxfail=30 2>&1 | tail -5) > gpurun_out/r05_s11_tests.log
   E=tools/experiments/small_batch_r05.py
-  (timeout 300 python $E --rows 5,8,12,16 --sets "default;sparse_transpose=2" 2>&1 | grep '^{') > gpurun_out/r05_s11.txt
+  (timeout 300 python $E --rows 5,8,12,16 --sets "default;skip_prepare_small=1" 2>&1 | grep '^{') > gpurun_out/r05_s11.txt
   (timeout 300 python $E --rows 8,16 --no-ws 2>&1 | grep '^{') >> gpurun_out/r05_s11.txt
   (timeout 300 python $E --bits 3 --rows 8,16 --sets "default;mfma_min_batch=5" 2>&1 | grep '^{') >> gpurun_out/r05_s11.txt
   (SQLLM_LIB=$PWD/squeezellm_amd/libsqllm_hip_ablation.so timeout 200 python tools/experiments/small_split_timeline.py --rows 16 2>&1 | grep -v amdgpu.ids) > gpurun_out/r05_s11_timeline.txt
@@ -124,7 +126,7 @@ s11)
 s12)
   mkdir -p gpurun_out
   E=tools/experiments/small_batch_r05.py
-  (timeout 300 python $E --rows 5,8,16 --sets "default;sparse_transpose=2" 2>&1 | grep '^{') > gpurun_out/r05_s12.txt
+  (timeout 300 python $E --rows 5,8,16 --sets "default;skip_prepare_small=1" 2>&1 | grep '^{') > gpurun_out/r05_s12.txt
   (SQLLM_LIB=$PWD/squeezellm_amd/libsqllm_hip_ablation.so timeout 200 python tools/experiments/small_split_timeline.py --rows 16 2>&1 | grep -v amdgpu.ids) > gpurun_out/r05_s12_timeline.txt
   cat gpurun_out/r05_s12.txt gpurun_out/r05_s12_timeline.txt
   ;;
