@@ -124,6 +124,9 @@ class QuantLinearLUT(nn.Module):
         return m
 
 
+_is_capturing = torch.cuda.is_current_stream_capturing
+
+
 class QuantLinearLUTFused(QuantLinearLUT):
     """Opt-in forward for fp16 activations: ONE kernel per call (sqllm_linear_f16) instead of the
     reference's four (`zeros`/`bias.clone()`, `x.float()`, the op, `y.to(fp16)`; quant.py:214-223,
@@ -133,19 +136,43 @@ class QuantLinearLUTFused(QuantLinearLUT):
     fp32), so the two differ by at most one fp16 rounding of the output.  Other dtypes take the
     parent's path."""
 
+    GRAPH_WS_MAX_BYTES = 4 << 20  # eager calls keep a second, graph-only workspace ready up to this size (decode batches)
+
     def _workspace(self, batch: int, device) -> torch.Tensor:
         """ONE zero-filled workspace per (device, stream), sized for the largest batch seen so far: a
         launch uses the first 8 * batch * N bytes and leaves them zero-filled, so smaller batches
         reuse the same buffer (a cache keyed by batch size would grow without bound under variable
         prompt lengths).  Two launches of one module that may overlap -- i.e. on different streams --
-        must not share the accumulator words, hence the stream in the key."""
+        must not share the accumulator words, hence the stream in the key.
+
+        Captured calls: a graph bakes the workspace's address in, and the capture stream is never the stream of the
+        warm-up calls, so a buffer keyed on it would be allocated AND zero-filled inside the capture -- a fill kernel in
+        front of every linear of the graph, replayed every time (that was 25 % of a replayed 7B pass: 484 against 603
+        tokens/s for the same kernels as a C-ABI sequence, BENCH_r05 `drop_in`).  Every eager call therefore also keeps
+        a graph-only workspace of its size ready (key (device, "graph"); up to GRAPH_WS_MAX_BYTES: decode batches), a
+        captured call takes that one -- the graph then holds the linear's kernel and nothing else -- and superseded
+        buffers are retired, not freed (older graphs may still point at them).  All graphs captured from this module
+        share it: replaying two of them CONCURRENTLY on different streams is not supported (set GRAPH_WS_MAX_BYTES = 0
+        on the module for private, in-graph workspaces).  Without a prepared buffer (no eager call of this size before
+        the capture) the workspace is a zero-filled temporary of the captured region."""
         cache = self.__dict__.setdefault("_ws", {})
         need = _lib.linear_workspace_bytes(self.outfeatures, batch)
+        if _is_capturing():
+            ws = cache.get((device, "graph"))
+            if ws is not None and ws.numel() >= need:
+                return ws
+            return torch.zeros(need, dtype=torch.uint8, device=device)  # (not remembered: it belongs to this graph's pool)
         key = (device, quant_cuda._raw_stream(device.index if device.index is not None else torch.cuda.current_device()))
         ws = cache.get(key)
         if ws is None or ws.numel() < need:
             ws = torch.zeros(need, dtype=torch.uint8, device=device)  # zero-filled once
             cache[key] = ws
+        if need <= self.GRAPH_WS_MAX_BYTES:
+            gws = cache.get((device, "graph"))
+            if gws is None or gws.numel() < need:
+                if gws is not None:
+                    cache.setdefault("retired", []).append(gws)
+                cache[(device, "graph")] = torch.zeros(need, dtype=torch.uint8, device=device)
         return ws
 
     def _check_csr_once(self) -> None:

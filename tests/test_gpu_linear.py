@@ -257,7 +257,7 @@ def test_fused_forward_keeps_one_workspace_across_batch_sizes(gpu):
         x = torch.randn((rows, K), device=gpu).half()
         y = mod(x if rows > 1 else x.reshape(1, 1, K)).reshape(rows, N)
         _check_fp16(y.cpu().numpy(), _exact(npl, x.cpu().numpy(), "hybrid"))
-        assert len(mod._ws) == 1
+        assert sorted(k[1] == "graph" for k in mod._ws if k != "retired") == [False, True]  # one eager buffer (per device and stream) + the graph-only one
         assert len(mod._desc) == 1  # (ONE descriptor per device and stream, not one per row count pinning a superseded workspace each)
         sizes.append(next(iter(mod._ws.values())).numel())
         assert int(next(iter(mod._ws.values())).count_nonzero()) == 0
@@ -383,3 +383,76 @@ def test_fused_descriptor_follows_routing_attributes_and_replaced_storage(gpu):
     want = ref(x).float()
     torch.cuda.synchronize()
     assert torch.allclose(y2, want, atol=2e-3 * float(want.abs().max())), float((y2 - want).abs().max())
+
+
+def test_captured_module_forwards_hold_their_kernels_only(gpu):
+    """seven fused linears captured through the torch MODULE must give the graph a C-ABI sequence gives --
+    one kernel node per linear.  (Until round 6 the module's workspace was keyed on the stream, the capture stream is never
+    the warm-up stream, and every linear of the graph got a `torch.zeros` fill kernel in front of it, replayed every time:
+    484 against 603 tokens/s on the 7B pass.)  Two replays against the eager result; a capture WITHOUT a warm-up call falls
+    back to an in-graph zero-filled temporary (two nodes per linear) and is still right."""
+    import ctypes
+
+    import torch
+
+    from squeezellm_amd import quant, synth
+
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def node_types(g):
+        raw = ctypes.c_void_p(g.raw_cuda_graph())
+        n = ctypes.c_size_t(0)
+        assert hip.hipGraphGetNodes(raw, None, ctypes.byref(n)) == 0
+        nodes = (ctypes.c_void_p * n.value)()
+        assert hip.hipGraphGetNodes(raw, nodes, ctypes.byref(n)) == 0
+        out = []
+        for nd in nodes:
+            ty = ctypes.c_int(-1)
+            assert hip.hipGraphNodeGetType(ctypes.c_void_p(nd), ctypes.byref(ty)) == 0
+            out.append(ty.value)
+        return out
+
+    K, N = 512, 328
+    mods = []
+    for i in range(7):
+        lay = synth.make_layer(K, N, 4 if i % 2 else 3, sparse_frac=0.01, topX=3, heavy_rows=1, bias=bool(i % 3), device=gpu, seed=50 + i)
+        m = quant.QuantLinearLUT.from_operands(lay)
+        m.__class__ = quant.QuantLinearLUTFused
+        mods.append(m)
+    x = torch.randn((1, 1, K), device=gpu).half()
+    for warm in (True, False):
+        if not warm:
+            for m in mods:
+                m.__dict__.pop("_ws", None)  # as if never called eagerly
+        outs = []
+
+        def run():
+            outs.clear()
+            with torch.no_grad():
+                for m in mods:
+                    outs.append(m(x))
+
+        if warm:
+            side = torch.cuda.Stream(gpu)
+            side.wait_stream(torch.cuda.current_stream(gpu))
+            with torch.cuda.stream(side):
+                run()
+            torch.cuda.current_stream(gpu).wait_stream(side)
+            torch.cuda.synchronize()
+            want = [o.clone() for o in outs]
+        g = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.cuda.graph(g):
+            run()
+        types = node_types(g)
+        if warm:
+            assert types == [0] * len(mods), types  # hipGraphNodeTypeKernel x 7: nothing but the linears
+        else:
+            assert len(types) == 2 * len(mods) and 10 not in types and 11 not in types, types  # + one zero fill each (kernel or memset node)
+        g.instantiate()
+        for _ in range(2):
+            for o in outs:
+                o.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            for o, w in zip(outs, want):
+                assert torch.equal(o, w)  # (the fused linear is bit-reproducible: integer accumulation)
