@@ -10,6 +10,15 @@ s1)
   (timeout 600 python bench.py 2>&1 | tail -3) > gpurun_out/r06_s1_bench.log
   tail -c 3000 gpurun_out/r06_s1_bench.log
   ;;
+s2)
+  # configs[3], per-op times by route: default routing, everything on the batch tiles / column-lane
+  # kernel (mfma_min_batch huge), and the workspace-less entry (no kernel in front, the sparse terms gather)
+  E=tools/experiments/small_batch_r05.py
+  (timeout 600 python $E --rows 1,2,3,4,5,6,8,12,16 --sets "default;mfma_min_batch=1048576" 2>&1 | grep '^{') > gpurun_out/r06_s2_routes.txt
+  (timeout 600 python $E --rows 5,6,8,12,16 --no-ws 2>&1 | grep '^{') > gpurun_out/r06_s2_routes_no_ws.txt
+  (timeout 600 python $E --rows 2,3,4 --sets "cols_min_batch=1073741824;cols_min_batch=1,cols_max_batch=4;cols_groups=0" 2>&1 | grep '^{') > gpurun_out/r06_s2_rows_2_4.txt
+  cat gpurun_out/r06_s2_routes.txt gpurun_out/r06_s2_routes_no_ws.txt gpurun_out/r06_s2_rows_2_4.txt
+  ;;
 first_use)
   # the parametrisations of test_wide_batch_routes_behind_options that failed once on a fresh box in round 5,
   # (A) the failing run's own prefix -- the file's first two tests in one fresh process -- $2 times; (B) each of the 24 cases at
