@@ -494,8 +494,9 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
       make_plan_mfma(op, &gm, 1, 2);
     }
   }
-  else if (takes_cols_path(op)) make_plan_cols(op, &gm);
-  else make_plan(op, &gm);
+  const bool cols = !mfma && takes_cols_path(op);
+  if (cols) make_plan_cols(op, &gm);
+  else if (!mfma) make_plan(op, &gm);
   const bool small_split = mfma && !wide && takes_small_split(op);
   if (small_split) {  // the fused small launch: CSR term folded into the dense workgroups, top-X slabs in the grid
     // (as launched with a workspace: vec transposed, 8-16 top-X workgroups, the dense ranges planned beside them)
@@ -512,7 +513,7 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   plan->csr_blocks = gm.csr_blocks;
   plan->topx_blocks = gm.topx_blocks;
   plan->grid_x = (mfma && !small_split) ? gm.dense_blocks : gm.dense_block0 + gm.dense_blocks;  // (wide batches: the sparse terms are a launch of their own)
-  const int rows_per_pass = wide ? (gm.batch > 0 ? gm.batch : 1) : mfma ? 16 * (row_blocks ? row_blocks : sqllm::mfma_row_blocks(gm.batch)) : sqllm::batch_tile(gm.batch);
+  const int rows_per_pass = wide ? (gm.batch > 0 ? gm.batch : 1) : mfma ? 16 * (row_blocks ? row_blocks : sqllm::mfma_row_blocks(gm.batch)) : cols ? sqllm::batch_tile(gm.batch) : sqllm::batch_tile_op(gm.batch);
   plan->grid_y = (gm.batch + rows_per_pass - 1) / rows_per_pass;
   return SQLLM_OK;
 }

@@ -456,8 +456,14 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
 // halving the live lookups won up to 18 %): the decode stages work on one column pair at a time
 // (16 live lookups instead of 32), which lets the batch-1 kernels fit 64 VGPRs, i.e. FOUR 8-wave
 // workgroups per CU; the wider batch tiles take what they need up to 128 (two per CU).
+// waves per SIMD the register allocation must leave room for (= 8-wave workgroups per CU x 2): batch 1 four workgroups (64
+// VGPRs), the 2- / 3-row and the 4-bit 4- / 5- / 6-row tiles three (80), everything wider two (128)
+constexpr int fused_min_waves(int bits, int bt, int abl) {
+  return (abl & 64) ? 8 : ((bt == 1 && SQLLM_HALF_STAGES) ? 8 : ((bt == 2 || bt == 3 || (bt >= 4 && bt <= 6 && bits == 4)) ? 6 : 4));
+}
+
 template <int BITS, int BT, int WAVES, int ABL, bool LIN>
-__global__ void __launch_bounds__(WAVES * 64, (ABL & 64) ? 8 : ((BT == 1 && SQLLM_HALF_STAGES) ? 8 : ((BT == 2 || (BT == 4 && BITS == 4)) ? 6 : 4)))
+__global__ void __launch_bounds__(WAVES * 64, fused_min_waves(BITS, BT, ABL))
 sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
   constexpr bool HALF = SQLLM_HALF_STAGES && BT == 1;  // wider batch tiles: the per-row x broadcasts would be live twice
   constexpr int T = WAVES * 64;

@@ -692,7 +692,16 @@ sqllm_fused_cols(const float* x, const GroupArgs ga) {
 
 template <int BITS, bool LIN>
 static hipError_t launch_bt(const LaunchArgs& a, hipStream_t stream) {
-  switch (batch_tile(a.ga.seg[0].gm.batch)) {
+  const int batch = a.ga.seg[0].gm.batch;
+  if constexpr (!LIN) {
+    switch (batch_tile_op(batch)) {  // (operator launches: tiles of exactly 3 / 5 / 6 rows too)
+      case 3: return launch_inst<BITS, 3, kWaves, 0, LIN>(a, stream);
+      case 5: return launch_inst<BITS, 5, kWaves, 0, LIN>(a, stream);
+      case 6: return launch_inst<BITS, 6, kWaves, 0, LIN>(a, stream);
+      default: break;
+    }
+  }
+  switch (batch_tile(batch)) {
     case 1: return launch_inst<BITS, 1, kWaves, 0, LIN>(a, stream);
     case 2: return launch_inst<BITS, 2, kWaves, 0, LIN>(a, stream);
     case 4: return launch_inst<BITS, 4, kWaves, 0, LIN>(a, stream);

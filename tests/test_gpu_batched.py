@@ -313,6 +313,34 @@ def test_column_lane_kernel_vs_oracle(qc, gpu, bits, kind, shape):
         _routing(0, 0, 0)
 
 
+@pytest.mark.parametrize("entry", ["module", "named"])
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("kind", ["dense", "spmv", "hybrid"])
+@pytest.mark.parametrize("shape", [(256, 192), (1024, 776), (32, 4), (96, 68)])
+def test_batch_tiles_every_row_count(qc, gpu, bits, kind, shape, entry):
+    """The batch tiles of the batch-1 kernel (sqllm_fused_matvec<BITS, BT>) forced for every batch size: tiles of exactly
+    1, 2, 3, 4, 5, 6 and 8 rows (7 rows ride the 8-row tile, 9+ go through in passes of 8) -- round 6 added the 3-, 5- and
+    6-row instantiations -- ragged shapes included, accumulating into a non-zero mul."""
+    import torch
+
+    K, N = shape
+    case = H.make_case(bits, K, N, sparse=0.03 if kind != "dense" else 0, topX=3 if kind == "hybrid" else 0,
+                       heavy_rows=1 if kind != "dense" and N >= 8 else 0, seed=K + N + bits)
+    t = H.to_torch(case, gpu)
+    try:
+        _routing(1 << 30, 1 << 30, 1 << 30)
+        for B in (1, 2, 3, 4, 5, 6, 7, 8, 11, 13, 14):
+            rng = np.random.default_rng(B)
+            x = rng.normal(size=(B, K)).astype(np.float32)
+            mul = rng.normal(size=(B, N)).astype(np.float32)
+            y = torch.from_numpy(mul.copy()).to(gpu)
+            H.call_op(qc, t, torch.from_numpy(x).to(gpu), y, kind, True, entry=entry)
+            torch.cuda.synchronize()
+            assert H.rel_err(y.cpu().numpy(), H.oracle_ref(case, x, mul, kind)) <= TOL_FP64, (B, K, N)
+    finally:
+        _routing(0, 0, 0)
+
+
 @pytest.mark.parametrize("bits", [3, 4])
 @pytest.mark.parametrize("kind", ["dense", "hybrid"])
 def test_column_lane_kernel_runs_groups(gpu, bits, kind):

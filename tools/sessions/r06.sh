@@ -19,6 +19,46 @@ s2)
   (timeout 600 python $E --rows 2,3,4 --sets "cols_min_batch=1073741824;cols_min_batch=1,cols_max_batch=4;cols_groups=0" 2>&1 | grep '^{') > gpurun_out/r06_s2_rows_2_4.txt
   cat gpurun_out/r06_s2_routes.txt gpurun_out/r06_s2_routes_no_ws.txt gpurun_out/r06_s2_rows_2_4.txt
   ;;
+s3)
+  # the 3- / 5- / 6-row batch tiles (round 6): parity, then same-box A/B of the 13B s45 layer by rows against the round-5 build
+  # (squeezellm_amd/ab/libr05.so = the tree at 87e8bf2) with the split kernel taking over from 5 (default until now), 7 and 9 rows
+  E=tools/experiments/small_batch_r05.py
+  (timeout 900 python -m pytest tests/test_gpu_batched.py tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider -k "test_batch_tiles_every_row_count or test_three_batched or test_small_shapes or test_llama13b" 2>&1 | tail -5) > gpurun_out/r06_s3_tests.log
+  tail -3 gpurun_out/r06_s3_tests.log
+  for rep in 1 2; do
+  (timeout 600 python $E --rows 2,3,4,5,6,7,8 --sets "default;mfma_min_batch=7;mfma_min_batch=9" 2>&1 | grep '^{') >> gpurun_out/r06_s3_w4.txt
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libr05.so timeout 600 python $E --rows 2,3,4,5,6,7,8 2>&1 | grep '^{') >> gpurun_out/r06_s3_w4.txt
+  done
+  (timeout 600 python $E --bits 3 --rows 2,3,4,5,6,8,9 2>&1 | grep '^{') > gpurun_out/r06_s3_w3.txt
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libr05.so timeout 600 python $E --bits 3 --rows 2,3,4,5,6,8,9 2>&1 | grep '^{') >> gpurun_out/r06_s3_w3.txt
+  python - <<'PY'
+import json
+for f in ("gpurun_out/r06_s3_w4.txt", "gpurun_out/r06_s3_w3.txt"):
+    print(f)
+    for l in open(f):
+        d = json.loads(l)
+        print(d["lib"], d["rows"], d["set"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
+PY
+  ;;
+ceiling)
+  # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
+  (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
+  (timeout 1200 python tools/ceiling_same_clock.py --loads-only /tmp/sp --raw-out gpurun_out/r06_stream_patterns.txt 2>&1 | grep '^{') > gpurun_out/r06_ceiling_same_clock.txt
+  cat gpurun_out/r06_ceiling_same_clock.txt
+  ;;
+timeline)
+  # where the sparse workgroups of a batch-1 s45 launch sit, and of the 2- / 4-row launches (item 2d)
+  L=$PWD/squeezellm_amd/libsqllm_hip_ablation.so
+  for sh in "4096x4096 1" "4096x4096 3" "4096x11008 2" "11008x4096 1"; do set -- $sh
+    (SQLLM_LIB=$L timeout 300 python tools/timeline.py --shape $1 --group $2 --bits 4 2>&1 | grep -v amdgpu.ids) >> gpurun_out/r06_timeline_batch1.txt
+    (SQLLM_LIB=$L timeout 300 python tools/timeline.py --shape $1 --group $2 --bits 4 --sparse 0.0045 --topx 10 2>&1 | grep -v amdgpu.ids) >> gpurun_out/r06_timeline_batch1.txt
+  done
+  for b in 2 4; do for sh in "5120x5120 1" "5120x5120 3" "5120x13824 2" "13824x5120 1"; do set -- $sh
+    (SQLLM_LIB=$L timeout 300 python tools/timeline.py --shape $1 --group $2 --bits 4 --batch $b 2>&1 | grep -v amdgpu.ids) >> gpurun_out/r06_timeline_rows_2_4.txt
+    (SQLLM_LIB=$L timeout 300 python tools/timeline.py --shape $1 --group $2 --bits 4 --sparse 0.0045 --topx 10 --batch $b 2>&1 | grep -v amdgpu.ids) >> gpurun_out/r06_timeline_rows_2_4.txt
+  done; done
+  cat gpurun_out/r06_timeline_batch1.txt gpurun_out/r06_timeline_rows_2_4.txt
+  ;;
 first_use)
   # the parametrisations of test_wide_batch_routes_behind_options that failed once on a fresh box in round 5,
   # (A) the failing run's own prefix -- the file's first two tests in one fresh process -- $2 times; (B) each of the 24 cases at
