@@ -95,7 +95,7 @@ int sqllm_launch(const sqllm_op* op, sqllm_stream_t stream);
  * device memory, 16-byte aligned, contents irrelevant before and after; sqllm_workspace_bytes(ops, n)
  * says how much the op (n = 1) or the group can use (0: none -- batch 1, batch tiles).  It serves one
  * launch at a time: launches on one stream may share it, concurrent streams may not.  What lives in it:
- *   mfma_min_batch..16 rows (fused small launch, only with sparse terms)  vec transposed, xT[k][rows rounded up to 8 / 16]: the
+ *   mfma_min_batch..16 rows (fused small launch: 4-bit from 7 rows, 3-bit from 9; only with sparse terms)  vec transposed, xT[k][rows rounded up to 8 / 16]: the
  *            CSR walk of the dense workgroups and the top-X slabs then read one cache line per k for all batch rows
  *            instead of one per row; behind it vec as three bf16 planes in fragment order ((K / 32 + 1) x 3 KB): the
  *            dense term loads its operands already split (one small kernel in front of the launch writes both);
@@ -292,8 +292,9 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     routing of the *_batched operators by batch size: cols_min_batch .. cols_max_batch
  *                     rows run on the column-lane kernel (lane = output column, vec in SGPRs),
  *                     mfma_min_batch rows and more on the matrix cores, everything else on the
- *                     batch tiles of the batch-1 kernel.  Defaults (value 0 = measured default, which
- *                     depends on the bit width; get_option returns the stored 0): 4-bit 2..4 / 5, 3-bit 2..8 / 9.
+ *                     batch tiles of the batch-1 kernel (tiles of exactly 1, 2, 3, 4, 5, 6 or 8 rows).  Defaults (value 0 =
+ *                     measured default, which depends on the bit width; get_option returns the stored 0): 4-bit 2..4 / 7
+ *                     (9 for an op of <= 16 MB of packed weights alone in its launch), 3-bit 2..8 / 9.
  *                     With the two cols_* options at their defaults the column-lane kernel is further reserved
  *                     for what it measured faster on: 4-bit, groups of three or more ops and single ops of
  *                     >= 20 MB packed weights; 3-bit, >= 16 MB at up to 4 rows or N >= 8192; setting either option

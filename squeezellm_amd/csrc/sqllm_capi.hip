@@ -286,25 +286,34 @@ int small_wgs_per_cu_of(const sqllm_op* op) {
   return v > 0 ? v : 2;
 }
 
-int mfma_min_batch_of(const sqllm_op* op) {
+// rows from which an op -- or, n_ops > 1, the group it leads -- leaves the batch tiles / the column-lane kernel for the matrix cores
+int mfma_min_batch_of(const sqllm_op* op, int n_ops = 1) {
   const int v = knobs().mfma_min_batch.load(std::memory_order_relaxed);
+  if (v > 0) return v;  // (an explicit value is taken at its word, whatever the shape)
   // 3-bit: 17 until round 4 -- from 9 rows the fused small-batch launch of the split matrix-core kernel beats the
-  // column-lane kernel (13B s45 layer 191-226 vs 270-286 us at 9-16 rows).  4-bit: from 5 rows it beats the batch tiles
-  // once its CSR role runs an 8-row tile (131 / 135 / 142 vs 143 / 146 / 153 us at 5 / 6 / 8 rows; at 3 bits it loses
-  // there, 162-177 vs 130-150: profiles/r04_small_batch_layer_min5.txt)
-  return v > 0 ? v : (op->bits == 4 ? 5 : 9);
+  // column-lane kernel (13B s45 layer 191-226 vs 270-286 us at 9-16 rows).
+  if (op->bits != 4) return 9;
+  // 4-bit: 5 in rounds 4-5 (the fused small launch against the 8-ROW tile, which a 5-row batch paid in full).  Round 6: batch
+  // tiles of exactly 5 and 6 rows, 78 / 80 VGPRs = three workgroups per CU like the 2- / 4-row ones -- same box, 13B s45 layer
+  // at 5 / 6 rows 121 / 121 us (fused small launch) -> 104 / 115 (tiles); at 7 / 8 rows the 8-row tile (96 VGPRs, two per CU)
+  // loses, 150 / 155 against 122 / 123 (profiles/r06_small_batch_tiles_5_6.txt).  Except for a SMALL op alone in its launch
+  // (<= 16 MB of packed weights: the 13B o_proj), whose fused small launch is mostly head, tail and the kernel in front of
+  // it: 8-row tile up to 8 rows (o_proj 16.5 against 22.4 us by events).
+  const double mb = (double)op->K * op->N / 2e6;
+  if (n_ops == 1 && mb <= 16.0) return 9;
+  return 7;
 }
 int cols_max_batch_of(const sqllm_op* op) {
   const int v = knobs().cols_max_batch.load(std::memory_order_relaxed);
   return v > 0 ? v : (op->bits == 3 ? 16 : 4);
 }
 
-bool takes_mfma_path(const sqllm_op* op) { return op->batch >= 1 && op->batch >= mfma_min_batch_of(op); }
+bool takes_mfma_path(const sqllm_op* op, int n_ops = 1) { return op->batch >= 1 && op->batch >= mfma_min_batch_of(op, n_ops); }
 
 // does this op (or the group it leads) run as the fused small launch of the split matrix-core kernel (sqllm_fused_small_split)?
-bool takes_small_split(const sqllm_op* op) {
+bool takes_small_split(const sqllm_op* op, int n_ops = 1) {
   if (op->K >= (1 << 26)) return false;  // (its folded CSR walk packs a local row beside the column)
-  return takes_mfma_path(op) && op->batch <= sqllm::kSmallSplitRows && knobs().mfma_split.load(std::memory_order_relaxed) &&
+  return takes_mfma_path(op, n_ops) && op->batch <= sqllm::kSmallSplitRows && knobs().mfma_split.load(std::memory_order_relaxed) &&
          knobs().mfma_fuse_small.load(std::memory_order_relaxed);
 }
 
@@ -377,7 +386,7 @@ bool group_takes_cols_path(const sqllm_op* ops, int n) {
   long long N = 0;
   for (int i = 0; i < n; ++i) N += ops[i].N;
   sum.N = N > 0x7fffffff ? 0x7fffffff : (int)N;
-  return !takes_mfma_path(&ops[0]) && sum.batch >= 1 && sum.batch >= cols_min_batch_of() && sum.batch <= cols_max_batch_of(&sum) && cols_pays(&sum, n);
+  return !takes_mfma_path(&ops[0], n) && sum.batch >= 1 && sum.batch >= cols_min_batch_of() && sum.batch <= cols_max_batch_of(&sum) && cols_pays(&sum, n);
 }
 
 bool takes_cols_path(const sqllm_op* op) {
@@ -671,7 +680,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
     return static_cast<int>(sqllm::launch_batched_cols(ops[0].bits, a, static_cast<hipStream_t>(stream)));
   }
-  if (!lin && takes_small_split(&ops[0])) {
+  if (!lin && takes_small_split(&ops[0], n)) {
     // up to 16 rows on the split matrix-core kernel: ONE launch for the whole group, sparse roles included
     sqllm::LaunchArgs a;
     a.ev_start = e0;
@@ -748,10 +757,10 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
     if (g_experimental.decorate) g_experimental.decorate(&a);  // (measurement library: timeline buffer)
     return static_cast<int>(sqllm::launch_small_split(ops[0].bits, a, static_cast<hipStream_t>(stream)));
   }
-  if (!lin && (takes_mfma_path(&ops[0]) || (n == 1 && takes_cols_path(&ops[0])))) {
+  if (!lin && (takes_mfma_path(&ops[0], n) || (n == 1 && takes_cols_path(&ops[0])))) {
     // batched operators: one launch per op (the members of a group only share their input) of the
     // matrix-core kernel (wide batches) or of the column-lane kernel (small ones)
-    const bool mfma = takes_mfma_path(&ops[0]);
+    const bool mfma = takes_mfma_path(&ops[0], n);
     WideScratch wsc;  // (transposed vec for the CSR role, planes + slabs for the wide form: see the struct)
     if (mfma) {
       int rc = validate(&ops[0]);  // (its kernels read vec by batch and K: shape errors first)
@@ -941,12 +950,12 @@ int sqllm_launch_groups(const sqllm_op* ops, const int32_t* group_sizes, int32_t
 int64_t sqllm_workspace_bytes(const sqllm_op* ops, int32_t n_ops) {
   if (!ops || n_ops < 1 || ops[0].batch < 2 || ops[0].K <= 0) return 0;  // (batch 1: one kernel, no scratch)
   int64_t need = 0;
-  if (takes_small_split(&ops[0])) {
+  if (takes_small_split(&ops[0], n_ops)) {
     bool any_sparse = false;
     for (int i = 0; i < n_ops; ++i) any_sparse = any_sparse || (ops[i].nnz > 0 && ops[i].rows) || (ops[i].full_rows && ops[i].topX > 0);
     if (any_sparse && knobs().sparse_transpose.load(std::memory_order_relaxed))
       need = sqllm::transpose_small_bytes(ops[0].batch, ops[0].K) + (knobs().small_planes.load(std::memory_order_relaxed) ? sqllm::small_planes_bytes(ops[0].K) : 0);
-  } else if (takes_mfma_path(&ops[0])) {
+  } else if (takes_mfma_path(&ops[0], n_ops)) {
     need = (int64_t)WideScratch::layout(ops, n_ops, false).total();
   }
   return (need + 255) / 256 * 256;

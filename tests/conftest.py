@@ -46,6 +46,28 @@ def pytest_collection_modifyitems(config, items):
 
 
 POISON_PATTERNS = (0x7FC00000, 0x7F7FFFFF)  # a quiet NaN; FLT_MAX (finite: survives a sum that would drop a NaN through a select)
+_lds_poison = None
+
+
+def _lds_poison_lib():
+    """tests/native/lds_poison.hip built in place (hipcc) and loaded: fills every CU's 160 KB of LDS with a pattern."""
+    global _lds_poison
+    if _lds_poison is None:
+        import ctypes
+        import shutil
+
+        import torch  # noqa: F401  (its libamdhip64 must be the HIP runtime the helper binds to)
+
+        src = os.path.join(ROOT, "tests", "native", "lds_poison.hip")
+        out = os.path.join(ROOT, "tests", "native", "liblds_poison.so")
+        if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+            hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+            subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", out], check=True, capture_output=True)
+        lib = ctypes.CDLL(out)
+        lib.lds_poison.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        lib.lds_poison.restype = ctypes.c_int
+        _lds_poison = lib
+    return _lds_poison
 
 
 @pytest.fixture(autouse=True)
@@ -53,7 +75,10 @@ def poisoned_workspaces(request, monkeypatch):
     """Every caller workspace handed to the library in a GPU test is filled with a poison pattern right before the launch
     (the Python module's per-stream buffer: quant_cuda._workspace; a pass's buffer: decode.OpSequence.launch / .profile), so
     a kernel that reads workspace bytes which no kernel of THIS launch wrote turns its output into NaN / 1e38 instead of
-    passing on the zeros of a fresh allocation.  The pattern is picked per test (hash of its node id): both get used."""
+    passing on the zeros of a fresh allocation.  The LDS of every CU gets the same treatment at the start of the test and
+    in front of those launches (tests/native/lds_poison.hip): LDS is not cleared between kernels, so a ticket or a slab read
+    before it is written would otherwise see whatever the previous kernel left -- right or wrong by the luck of placement.
+    The pattern is picked per test (hash of its node id): both get used."""
     if request.node.get_closest_marker("gpu") is None:
         yield
         return
@@ -63,8 +88,18 @@ def poisoned_workspaces(request, monkeypatch):
 
     from squeezellm_amd import decode, quant_cuda
 
-    pattern = POISON_PATTERNS[zlib.crc32(request.node.nodeid.encode()) & 1]
-    pattern -= (1 << 32) if pattern >= (1 << 31) else 0
+    if not torch.cuda.is_available():  # (the `gpu` fixture reports that)
+        yield
+        return
+    upattern = POISON_PATTERNS[zlib.crc32(request.node.nodeid.encode()) & 1]
+    pattern = upattern - ((1 << 32) if upattern >= (1 << 31) else 0)
+    lds = _lds_poison_lib()
+    sink = torch.zeros(4, dtype=torch.int32, device="cuda:0")
+
+    def poison_lds():
+        if not torch.cuda.is_current_stream_capturing():
+            rc = lds.lds_poison(torch.cuda.current_stream().cuda_stream, upattern, sink.data_ptr())
+            assert rc == 0, rc
 
     def fill(ws):
         n = ws.numel() // 4 * 4
@@ -78,6 +113,7 @@ def poisoned_workspaces(request, monkeypatch):
         if ws is not None:
             with torch.cuda.device(dev):
                 fill(ws)
+                poison_lds()
         return ws
 
     real_launch, real_profile = decode.OpSequence.launch, decode.OpSequence.profile
@@ -85,6 +121,8 @@ def poisoned_workspaces(request, monkeypatch):
     def launch(self):
         if self._ws is not None:
             fill(self._ws)
+        with torch.cuda.device(self.device):
+            poison_lds()
         return real_launch(self)
 
     def profile(self, reps=3):
@@ -95,7 +133,10 @@ def poisoned_workspaces(request, monkeypatch):
     monkeypatch.setattr(quant_cuda, "_workspace", workspace)
     monkeypatch.setattr(decode.OpSequence, "launch", launch)
     monkeypatch.setattr(decode.OpSequence, "profile", profile)
+    with torch.cuda.device(0):
+        poison_lds()
     yield
+    assert int(sink[0]) == 0, "the LDS poison kernel read back something it had not written"
 
 
 @pytest.fixture(scope="session")

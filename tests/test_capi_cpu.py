@@ -92,9 +92,15 @@ def test_plan_geometry():
     _lib.set_option("cols_min_batch", 1 << 30)  # switched off: the batch tiles of the batch-1 kernel
     assert _lib.plan_query(3, 5120, 13824, batch=4)["dense_blocks"] == pc["col_tiles"] * _lib.plan_query(3, 5120, 13824, batch=4)["k_slices"]
     _lib.set_option("cols_min_batch", 0)
-    # batches from `mfma_min_batch` (4-bit 5, 3-bit 9) rows up take the matrix-core kernel: passes of 16 / 32 / 64 rows
-    assert _lib.get_option("mfma_min_batch") == 0  # = the measured default: 5 rows at 4 bits, 9 at 3
-    assert _lib.plan_query(4, 4096, 4096, batch=8)["grid_y"] == 1 and _lib.plan_query(3, 4096, 4096, batch=16)["grid_y"] == 1  # (3-bit: matrix cores from 9 rows since round 4)
+    # batches from `mfma_min_batch` (4-bit 7 -- 9 for an op of <= 16 MB alone in its launch --, 3-bit 9) rows up take the matrix-core
+    # kernel: passes of 16 / 32 / 64 rows; below, batch tiles of exactly 1, 2, 3, 4, 5, 6 or 8 rows (round 6: 3, 5, 6)
+    assert _lib.get_option("mfma_min_batch") == 0  # = the measured default
+    assert _lib.plan_query(4, 4096, 11008, batch=8)["grid_y"] == 1 and _lib.plan_query(3, 4096, 4096, batch=16)["grid_y"] == 1  # (3-bit: matrix cores from 9 rows since round 4)
+    for b, tiles in ((3, 3), (5, 5), (6, 6), (7, 8)):  # (batch, rows per pass) on the batch tiles: one pass, K slices per column tile
+        pt = _lib.plan_query(4, 4096, 4096, batch=b)
+        assert pt["grid_y"] == 1 and pt["dense_blocks"] == pt["col_tiles"] * pt["k_slices"], (b, pt)
+    assert _lib.plan_query(4, 4096, 4096, batch=8)["dense_blocks"] == 64 * _lib.plan_query(4, 4096, 4096, batch=8)["k_slices"]  # 8.4 MB alone: 8-row tile
+    assert _lib.plan_query(4, 4096, 11008, batch=6)["dense_blocks"] == 172 * _lib.plan_query(4, 4096, 11008, batch=6)["k_slices"]  # 6 rows: tiles whatever the size
     assert _lib.plan_query(3, 4096, 4096, batch=17)["grid_y"] == 1
     assert _lib.plan_query(4, 4096, 4096, batch=9)["grid_y"] == 1
     assert _lib.plan_query(4, 4096, 4096, batch=33)["grid_y"] == 1
@@ -113,7 +119,7 @@ def test_plan_geometry():
     # (planned as launched with a workspace: vec transposed, the top-X slabs shared by few workgroups of several slabs each --
     # an op alone in its launch: up to 24, or 16 from 25 slabs; in a group 8 / 16 per op -- and the dense ranges cut for the
     # slots they leave: ONE round of workgroups in all)
-    for b in (5, 8, 16):
+    for b in (7, 8, 16):
         pf = _lib.plan_query(4, 5120, 13824, nnz=330_000, topX=10, batch=b)
         assert pf["csr_blocks"] == 0 and pf["topx_blocks"] == 20 and pf["grid_x"] == 24 + pf["dense_blocks"] <= 512, (b, pf)
     assert _lib.plan_query(4, 13824, 5120, nnz=330_000, topX=10, batch=8)["topx_blocks"] == 16

@@ -244,16 +244,32 @@ def test_fused_small_launch_with_planes(qc, gpu, bits, K, N, batch, vec):
     if vec == "one-fp32-value":
         x[batch - 1, K - 3] = np.float32(0.123456789)
     mul = rng.normal(0, 0.5, size=(batch, N)).astype(np.float32)
+    from squeezellm_amd import _lib
+
     t = H.to_torch(case, gpu)
     yt = torch.from_numpy(mul.copy()).to(gpu)
-    H.call_op(qc, t, torch.from_numpy(x).to(gpu), yt, "hybrid", True)
-    torch.cuda.synchronize()
+    try:
+        _lib.set_option("mfma_min_batch", 5)  # (explicit: by default such small single ops stay on the batch tiles up to 8 rows)
+        H.call_op(qc, t, torch.from_numpy(x).to(gpu), yt, "hybrid", True)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_option("mfma_min_batch", 0)
     assert H.rel_err(yt.cpu().numpy(), H.oracle_ref(case, x, mul, "hybrid")) <= TOL_FP64
+
+
+@pytest.fixture
+def small_launch_from_5_rows():
+    """the fused small launch from 5 rows whatever the shape (the default keeps 5 / 6 rows, and small single ops up to 8, on the batch tiles)"""
+    from squeezellm_amd import _lib
+
+    _lib.set_option("mfma_min_batch", 5)
+    yield
+    _lib.set_option("mfma_min_batch", 0)
 
 
 @pytest.mark.parametrize("bits", [3, 4])
 @pytest.mark.parametrize("batch", [5, 8, 16])
-def test_fused_small_launch_sparse_edge_cases(qc, gpu, bits, batch):
+def test_fused_small_launch_sparse_edge_cases(qc, gpu, bits, batch, small_launch_from_5_rows):
     """The edge cases of tests/test_gpu_parity.py::test_sparse_edge_cases on the fused small launch, whose dense workgroups
     walk the CSR rows of their own tile (csr_tile_fold_staged): an empty CSR, empty rows at both ends and in the middle beside
     rows that hold most of the non-zeros, duplicate top-X indices, one tile's share larger than a staging pass (4096 non-zeros:
@@ -435,11 +451,12 @@ LLAMA13B = [(5120, 5120), (5120, 13824), (13824, 5120)]
 
 @pytest.mark.parametrize("bits", [3, 4])
 @pytest.mark.parametrize("K,N", LLAMA13B)
-@pytest.mark.parametrize("batch", [2, 8, 16])
+@pytest.mark.parametrize("batch", [2, 5, 8, 16])
 @pytest.mark.parametrize("entry", H.ENTRIES)
 def test_llama13b_shapes_batched_hybrid(qc, gpu, bits, K, N, batch, entry):
     """BASELINE config 4 at full size on all three 13B shapes, against the C oracle (batch 2: batch tiles / column-lane
-    kernel; 8 and 16: the fused small launch at 4 bits, 16 only at 3), through all three entries."""
+    kernel; 5: the 5-row batch tile; 8: the fused small launch at 4 bits -- the 8-row tile for 5120 x 5120, a small op alone in
+    its launch --, tiles / column-lane kernel at 3 bits; 16: the fused small launch), through all three entries."""
     case = H.make_case(bits, K, N, sparse=0.0045, topX=10, heavy_rows=10, seed=13)
     x, mul, got = run_batched(qc, gpu, case, "hybrid", batch, entry=entry)
     ref = H.c_matvec(H.c_oracle(), case, x, mul, batched=True)

@@ -81,9 +81,11 @@ def test_nonfinite_operands_follow_the_reference(qc, gpu, bits, batch, poison, f
         ref = H.oracle_ref(case, x, mul, "hybrid")
     assert not np.isfinite(ref).all(), "the poison must reach an output"
     try:
+        _lib.set_option("mfma_min_batch", 5)  # (5 rows on the fused small launch: the default keeps them on the batch tiles, plain fp32 chains)
         if form == "wide":
             _lib.set_option("mfma_wide_min_batch", 64)
         got = _run(qc, gpu, case, x, mul, entry)
     finally:
         _lib.set_option("mfma_wide_min_batch", 0)
+        _lib.set_option("mfma_min_batch", 0)
     _same_pattern(got, ref)

@@ -39,6 +39,7 @@ def threshold():
 
 out = {"threshold_start": threshold()}
 lib = _lib.load()
+_lib.set_option("mfma_min_batch", 5)  # (explicit: these small shapes would otherwise stay on the batch tiles up to 8 rows, which need no workspace)
 for batch in (8, 64, 256):
     case = H.make_case(4, 512, 320, sparse=0.02, topX=3, heavy_rows=1, seed=batch)
     t = H.to_torch(case, dev)

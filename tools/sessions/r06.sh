@@ -40,6 +40,33 @@ for f in ("gpurun_out/r06_s3_w4.txt", "gpurun_out/r06_s3_w3.txt"):
         print(d["lib"], d["rows"], d["set"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
 PY
   ;;
+s4)
+  # new default routing (4-bit: tiles up to 6 rows, small single ops up to 8): full suite with workspaces AND LDS poisoned, same-box
+  # A/B against the round-5 build and against the explicit thresholds, 3-bit tiles against the column-lane kernel, bench line
+  E=tools/experiments/small_batch_r05.py
+  (timeout 1800 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider 2>&1 | tail -40) > gpurun_out/r06_s4_tests.log
+  tail -4 gpurun_out/r06_s4_tests.log
+  for rep in 1 2; do
+  (timeout 600 python $E --rows 1,2,3,4,5,6,7,8,12,16 --sets "default;mfma_min_batch=7;mfma_min_batch=5" 2>&1 | grep '^{') >> gpurun_out/r06_s4_w4.txt
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libr05.so timeout 600 python $E --rows 1,2,3,4,5,6,7,8,12,16 2>&1 | grep '^{') >> gpurun_out/r06_s4_w4.txt
+  done
+  (timeout 600 python $E --bits 3 --rows 2,3,4,5,6,8 --sets "default;cols_min_batch=1073741824" 2>&1 | grep '^{') > gpurun_out/r06_s4_w3.txt
+  python - <<'PY'
+import json
+for f in ("gpurun_out/r06_s4_w4.txt", "gpurun_out/r06_s4_w3.txt"):
+    print(f)
+    for l in open(f):
+        d = json.loads(l)
+        print(d["lib"], d["rows"], d["set"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
+PY
+  (timeout 900 python bench.py 2>/dev/null | grep '^{') > gpurun_out/r06_s4_bench.json
+  python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r06_s4_bench.json"))
+print(d["value"], d["roofline"]["frac"], {k: v.get("tokens_per_s") for k, v in d["drop_in"].items() if isinstance(v, dict) and "tokens_per_s" in v})
+print({k: v["ms_per_decoder_layer"] for k, v in d["sub_records"]["13b-w4-s45-batched"].items() if isinstance(v, dict) and "ms_per_decoder_layer" in v})
+PY
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
