@@ -609,8 +609,8 @@ def drop_in_legs(layers, xs, dev, args, sync, model_layers, per_layer):
     t_op = timed(g3.replay, 20)
     rec["fused_linear_kernel_vs_operator"] = {"fused_linear_sequence_ms": round(t_lin, 4), "operator_sequence_ms": round(t_op, 4),
                                               "overhead_pct": round((t_lin / t_op - 1) * 100, 1),
-                                              "note": "C-ABI sequences, one launch per linear each, graph replay; the gap between this and "
-                                                      "fused_linear_graph is the torch-captured module path, not the kernel"}
+                                              "note": "C-ABI sequences, one launch per linear each, graph replay; fused_linear_graph (the same "
+                                                      "kernels captured through the torch module) should read within a few percent of the first"}
     del g2, g3, lin_seq, op_seq, ys16, ys32
     rec["note"] = (f"forward_* and fused_linear_graph: {n_dec} of {model_layers} decoder layers timed, scaled; fp16 activations; "
                    "the headline `value` needs the grouped-launch entry point (sqllm_launch_groups / OpSequence), "

@@ -376,6 +376,9 @@ bool cols_pays(const sqllm_op* op, int n_ops) {
   if (knobs().cols_min_batch.load(std::memory_order_relaxed) > 0 || knobs().cols_max_batch.load(std::memory_order_relaxed) > 0) return true;
   const double mb = (double)op->K * op->N * op->bits / 8e6;  // (of a group: the sum of its ops)
   if (op->bits == 4) return n_ops >= 3 || (n_ops == 1 && mb >= 20.0);
+  // (3-bit, round 6: at exactly 3 / 5 rows the batch tiles of that many rows beat the column-lane kernel, which serves them in its
+  // 4- / 8-row passes -- same box, 13B s45 layer 84 -> 78 / 120 -> 107 us: profiles/r06_small_batch_w3_tiles_vs_cols.txt)
+  if (op->batch == 3 || op->batch == 5) return false;
   if (op->batch <= 4 && mb >= 16.0) return true;
   return op->N >= 8192;
 }
