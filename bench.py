@@ -181,7 +181,7 @@ def rocprof_kernel_us_per_launch(config_name: str, fused: bool):
     names = {"7b-w4-s0": "kt_w4.summary.txt", "7b-w3-s45": "kt_w3.summary.txt", "7b-w4-s45": "kt_w4s45.summary.txt"}
     if config_name not in names or not fused:
         return None, None
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{names[config_name]}")
         try:
             lines = open(path).read().splitlines()
@@ -225,7 +225,7 @@ def pmc_traffic_per_launch(config_name: str, fused: bool):
         n = sum(int(a) for a, _ in rows)
         return sum(int(a) * float(b.replace(",", "")) for a, b in rows) / n
 
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):  # newest committed round first
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):  # newest committed round first
         fetch = mean_kib(f"{rnd}_{names[config_name][0]}", "FETCH_SIZE")
         if fetch is None:
             continue

@@ -60,13 +60,19 @@ def _lds_poison_lib():
 
         src = os.path.join(ROOT, "tests", "native", "lds_poison.hip")
         out = os.path.join(ROOT, "tests", "native", "liblds_poison.so")
-        if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-            hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-            subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", out], check=True, capture_output=True)
-        lib = ctypes.CDLL(out)
-        lib.lds_poison.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
-        lib.lds_poison.restype = ctypes.c_int
-        _lds_poison = lib
+        try:
+            if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+                hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+                subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", out], check=True, capture_output=True)
+            lib = ctypes.CDLL(out)
+            lib.lds_poison.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+            lib.lds_poison.restype = ctypes.c_int
+            _lds_poison = lib
+        except (OSError, subprocess.CalledProcessError) as e:  # no hipcc on this host and no prebuilt helper: the tests still run, unpoisoned
+            import warnings
+
+            warnings.warn(f"tests/native/lds_poison.hip could not be built or loaded ({e}): LDS is not poisoned in this run")
+            _lds_poison = False
     return _lds_poison
 
 
@@ -97,7 +103,7 @@ def poisoned_workspaces(request, monkeypatch):
     sink = torch.zeros(4, dtype=torch.int32, device="cuda:0")
 
     def poison_lds():
-        if not torch.cuda.is_current_stream_capturing():
+        if lds and not torch.cuda.is_current_stream_capturing():
             rc = lds.lds_poison(torch.cuda.current_stream().cuda_stream, upattern, sink.data_ptr())
             assert rc == 0, rc
 

@@ -67,6 +67,17 @@ print(d["value"], d["roofline"]["frac"], {k: v.get("tokens_per_s") for k, v in d
 print({k: v["ms_per_decoder_layer"] for k, v in d["sub_records"]["13b-w4-s45-batched"].items() if isinstance(v, dict) and "ms_per_decoder_layer" in v})
 PY
   ;;
+micro)
+  # batch-1 micro-variants of the decode step, same-box A/B through variant builds (squeezellm_amd/ab/lib<v>.so, built from patched copies of
+  # csrc/: LABNOTES.md round 6, 4): head = HEAD; v1 = two independent FMA chains per column pair; v2 = s_setprio 1 for the younger half of a
+  # workgroup's waves; v4 = s_setprio 1 for every dense wave (above the sparse roles' waves).  Plus the small-op geometry sweep (item 3c).
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libv1.so timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider -k "llama7b or small_shapes" 2>&1 | tail -2) > gpurun_out/r06_micro_parity.txt
+  (bash tools/ab_libs.sh "head v1 v2 v4" "7b-w4-s0 7b-w3-s45 7b-w4-s45" 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/r06_micro_ab.txt
+  cat gpurun_out/r06_micro_parity.txt gpurun_out/r06_micro_ab.txt
+  (timeout 900 python tools/experiments/small_op_geometry.py --bits 4 2>&1 | grep '^{') > gpurun_out/r06_small_op_geometry.txt
+  (timeout 900 python tools/experiments/small_op_geometry.py --bits 3 2>&1 | grep '^{') >> gpurun_out/r06_small_op_geometry.txt
+  cat gpurun_out/r06_small_op_geometry.txt
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
