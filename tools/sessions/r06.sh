@@ -78,6 +78,41 @@ micro)
   (timeout 900 python tools/experiments/small_op_geometry.py --bits 3 2>&1 | grep '^{') >> gpurun_out/r06_small_op_geometry.txt
   cat gpurun_out/r06_small_op_geometry.txt
   ;;
+prio)
+  # the adopted rule (dense waves at s_setprio 1 iff the batch-1 launch has sparse roles and fits the resident slots): libv5.so = this tree, libhead.so = the tree before it
+  (bash tools/ab_libs.sh "head v5" "7b-w3-s45 7b-w4-s45 13b-w4-s45 65b-w3-s45 7b-w4-s0" 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/r06_dense_priority_ab.txt
+  cat gpurun_out/r06_dense_priority_ab.txt
+  ;;
+prio2)
+  # does the priority help the multi-round launches too once the sparse workgroups come LAST in the grid (option sparse_last)?  libv6.so = priority for every
+  # batch-1 launch with sparse roles; libv5.so = the adopted rule (only launches that fit the resident slots)
+  cp squeezellm_amd/libsqllm_hip.so /tmp/lib_orig.so
+  for rep in 1 2 3; do for v in "v5 sparse_last=0" "v5 sparse_last=1" "v6 sparse_last=0" "v6 sparse_last=1"; do set -- $v
+    cp squeezellm_amd/ab/lib$1.so squeezellm_amd/libsqllm_hip.so
+    for c in 7b-w3-s45 7b-w4-s45 13b-w4-s45; do SQLLM_OPTIONS=$2 timeout 200 python bench.py --config $c --no-cpu-baseline --no-sub-records 2>&1 | grep "^{" | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('$1', '$2', d['config']['config_name'], d['value'], {k: v['us_mean'] for k, v in d['per_layer_us'].items()})
+"; done; done; done > gpurun_out/r06_dense_priority_sparse_last.txt
+  cp /tmp/lib_orig.so squeezellm_amd/libsqllm_hip.so
+  cat gpurun_out/r06_dense_priority_sparse_last.txt
+  ;;
+prio3)
+  # the adopted rule (libv7.so = this tree): sparse workgroups first + dense priority when the batch-1 launch fits the resident slots, sparse workgroups last otherwise;
+  # against libv5.so (priority rule only) and libhead.so (neither); then the full GPU suite on the new ordering, and the same switch forced on the batch tiles
+  (bash tools/ab_libs.sh "head v5 v7" "7b-w3-s45 7b-w4-s45 13b-w4-s45 65b-w3-s45" 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/r06_sparse_order_ab.txt
+  cat gpurun_out/r06_sparse_order_ab.txt
+  (timeout 1800 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider 2>&1 | tail -5) > gpurun_out/r06_prio3_tests.log
+  tail -3 gpurun_out/r06_prio3_tests.log
+  E=tools/experiments/small_batch_r05.py
+  (timeout 600 python $E --rows 2,3,4,5,6 --sets "default;sparse_last=1;sparse_last=2;default" 2>&1 | grep '^{') > gpurun_out/r06_sparse_order_tiles.txt
+  python - <<'PY'
+import json
+for l in open("gpurun_out/r06_sparse_order_tiles.txt"):
+    d = json.loads(l)
+    print(d["rows"], d["set"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
+PY
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
