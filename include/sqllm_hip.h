@@ -286,9 +286,7 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *   "target_wgs"      dense workgroups to aim for (default 0 = 1 x CU count for layers <= 12 MB,
  *                     3 x CU count above)
  *   "groups_per_wave" force the K units each wave walks (default 0 = derived from target_wgs)
- *   "sparse_last"     where the CSR / top-X workgroups of a batch-1 launch sit in its grid.  0 (default) = by launch size: first, with the
- *                     dense workgroups' waves at s_setprio 1, when the whole launch is resident at once (<= 4 workgroups per CU: o_proj
- *                     -4...-7 %), after the dense workgroups otherwise (gate/up -3...-5 %); 1 = always last; 2 = always first
+ *   "sparse_last"     1 = CSR / top-X workgroups after the dense ones in the grid (default 0: first)
  *   "cu_count"        override the CU count used for planning (GPU-less tests)
  *   "mfma_min_batch", "cols_min_batch", "cols_max_batch"
  *                     routing of the *_batched operators by batch size: cols_min_batch .. cols_max_batch
@@ -357,7 +355,7 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     scratch on the current device per check); skipped while the stream is capturing.
  *                     Meant for the fused linear, which counts on `rows` to detect completion.
  * Returns SQLLM_E_OPTION for an unknown name and for a value outside the option's range: switches take 0 / 1 only,
- * "sparse_last" 0..2, "small_wgs_per_cu" 0..8, "cu_count" up to 65536, "target_wgs" / "groups_per_wave" up to 2^24, the *_min_batch /
+ * "small_wgs_per_cu" 0..8, "cu_count" up to 65536, "target_wgs" / "groups_per_wave" up to 2^24, the *_min_batch /
  * *_max_batch thresholds any non-negative int.  No value of any option changes a result beyond fp32 round-off. */
 int sqllm_set_option(const char* name, int value);
 int sqllm_get_option(const char* name, int* value);

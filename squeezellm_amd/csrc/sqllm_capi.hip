@@ -142,45 +142,29 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch, int
   gm->topx_blocks = gm->topX ? (op->K + sqllm::kTopxRows - 1) / sqllm::kTopxRows : 0;
   // dense blocks start at a multiple of 8 so that (dense id % 8) is the XCD of the workgroup
   gm->dense_block0 = (gm->csr_blocks + gm->topx_blocks + 7) / 8 * 8;
-  // option sparse_last: 1 = the sparse workgroups always last in the grid, 2 = always first, 0 = by launch (order_sparse_roles, below:
-  // planned first here, moved behind the dense workgroups there)
-  gm->sparse_last = knobs().sparse_last.load(std::memory_order_relaxed) == 1 ? 1 : 0;
+  gm->sparse_last = knobs().sparse_last.load(std::memory_order_relaxed);
   if (gm->sparse_last) gm->dense_block0 = gm->csr_blocks + gm->topx_blocks;  // grid = dense + sparse
   if (g_experimental.csr_ablation_bits) gm->sparse_last |= g_experimental.csr_ablation_bits() << 1;  // (measurement library)
 }
 
-// Where the CSR / top-X workgroups of a BATCH-1 operator launch sit in its grid, and whose waves win the issue arbitration
-// (round 6; `segs` = the launch's segments as make_plan left them, `total` = its workgroups, padding included):
-//  * a launch whose workgroups are all resident at once (four 8-wave workgroups per CU): sparse workgroups FIRST, as before, and the
-//    dense waves at s_setprio 1 (dense_role) -- the sparse workgroups are chains of memory round trips that finish before the dense tail
-//    anyway, and every issue slot they win is taken from an issue-bound decode: 7B s45 o_proj 5.0 -> 4.7 us (3-bit) / 5.04 -> 4.85
-//    (4-bit), 3-bit down_proj 7.8 -> 7.4;
-//  * a launch of more workgroups than that: sparse workgroups LAST (and no priority).  In front of the grid they hold, for the 3-5 us
-//    of their lives, slots that the dense workgroups of the first round would have taken: 7B gate/up 13.0 -> 12.55 us (3-bit) /
-//    13.9 -> 13.2 (4-bit), 13B gate/up 21.1 -> 20.4, 4-bit q/k/v 9.0 -> 8.7 -- while the same order costs o_proj +12 % (its sparse
-//    workgroups then START after 512 dense ones and are the launch's tail), which is why "sparse_last" as a global switch measured
-//    as no change in rounds 3 and 5 (profiles/r06_dense_priority_sparse_last.txt).
-// Returns the launch's workgroup count after the move (the segments' block ranges shrink by their padding in front of the dense ids).
-int order_sparse_roles(sqllm::Segment* segs, int n, int batch, int total) {
-  const int mode = knobs().sparse_last.load(std::memory_order_relaxed);
-  if (batch > 1) return total;
+// Whose waves win the issue arbitration in a 3-BIT BATCH-1 operator launch with sparse roles (round 6; `segs` = the launch's segments as
+// make_plan left them, `total` = its workgroups): when all of them are resident at once (four 8-wave workgroups per CU) the dense
+// workgroups' waves run at s_setprio 1 (dense_role), above the CSR / top-X roles' waves -- those are chains of memory round trips that
+// finish before the dense tail anyway, and every issue slot they win is taken from an issue-bound decode.  Same-box A/Bs on two boxes
+// (profiles/r06_dense_priority_ab.txt, r06_sparse_order_ab.txt): 7B w3 s45 +2.5 / +3.5 % tokens/s (o_proj 5.1 -> 4.7-4.9 us,
+// down_proj 8.1 -> 7.4-8.0, q/k/v 8.6 -> 8.3 on one box).  NOT set:
+//  * at 4 bits: o_proj -4 % on one box, +3 % on the other, the pass +-0 / -2 %;
+//  * in launches of more workgroups than the chip holds: the low-priority sparse workgroups in front of the grid then hold the slots
+//    the next dense workgroups wait for (gate/up +5 %).  Moving them BEHIND the dense workgroups for such launches (option sparse_last
+//    per launch) was built too: -3...-9 % per launch on one box (7B / 13B gate/up, 65B: +6 % tokens/s), +3...+12 % on the other
+//    (4-bit q/k/v and down_proj, 13B: -4 % tokens/s) -- not adopted; as a global switch it costs o_proj +12 % everywhere, which
+//    is why it measured as "no change" in rounds 3 and 5.
+void set_dense_priority(sqllm::Segment* segs, int n, int bits, int batch, int total) {
+  if (bits != 3 || batch > 1 || total > 4 * cu_count() || (segs[0].gm.sparse_last & 1)) return;
   bool sparse = false;
   for (int i = 0; i < n; ++i) sparse = sparse || segs[i].gm.csr_blocks + segs[i].gm.topx_blocks > 0;
-  if (!sparse) return total;
-  const bool fits = total <= 4 * cu_count();
-  if (mode == 0 && !fits) {
-    total = 0;
-    for (int i = 0; i < n; ++i) {
-      sqllm::KernelGeom& gm = segs[i].gm;
-      gm.sparse_last |= 1;
-      gm.dense_block0 = gm.csr_blocks + gm.topx_blocks;
-      total += (gm.dense_block0 + gm.dense_blocks + 7) / 8 * 8;
-    }
-    return total;
-  }
-  if (fits && !(segs[0].gm.sparse_last & 1))
+  if (sparse)
     for (int i = 0; i < n; ++i) segs[i].gm.dense_prio = 1;
-  return total;
 }
 
 void fill_segment(const sqllm_op* op, sqllm::Segment* sg) {
@@ -468,7 +452,7 @@ int sqllm_set_option(const char* name, int value) {
       {"target_wgs", &Knobs::target_wgs, 1 << 24},
       {"groups_per_wave", &Knobs::groups_per_wave, 1 << 24},
       {"cu_count", &Knobs::cu_count, 1 << 16},  // for GPU-less planning tests
-      {"sparse_last", &Knobs::sparse_last, 2},
+      {"sparse_last", &Knobs::sparse_last, 1},
       {"cols_groups", &Knobs::cols_groups, 1},
       {"mfma_min_batch", &Knobs::mfma_min_batch, 0x7fffffff},  // (a huge value: never)
       {"cols_min_batch", &Knobs::cols_min_batch, 0x7fffffff},
@@ -544,13 +528,7 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   }
   const bool cols = !mfma && takes_cols_path(op);
   if (cols) make_plan_cols(op, &gm);
-  else if (!mfma) {
-    make_plan(op, &gm);
-    sqllm::Segment one;  // (as launched alone: where its sparse workgroups sit depends on the launch's size)
-    one.gm = gm;
-    (void)order_sparse_roles(&one, 1, op->batch, (gm.dense_block0 + gm.dense_blocks + 7) / 8 * 8);
-    gm = one.gm;
-  }
+  else if (!mfma) make_plan(op, &gm);
   const bool small_split = mfma && !wide && takes_small_split(op);
   if (small_split) {  // the fused small launch: CSR term folded into the dense workgroups, top-X slabs in the grid
     // (as launched with a workspace: vec transposed, 8-16 top-X workgroups, the dense ranges planned beside them)
@@ -946,17 +924,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
   }
   for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
   for (int i = n; i < sqllm::kMaxSegments; ++i) memset(&a.ga.seg[i], 0, sizeof(sqllm::Segment));
-  if (!lin) {  // batch-1 operator launches: the sparse workgroups' place in the grid and the dense waves' priority, by launch size
-    const int total = order_sparse_roles(a.ga.seg, n, ops[0].batch, block);
-    if (total != block) {
-      block = 0;
-      for (int i = 0; i < n; ++i) {
-        a.ga.block0[i] = block;
-        block += (a.ga.seg[i].gm.dense_block0 + a.ga.seg[i].gm.dense_blocks + 7) / 8 * 8;
-      }
-      for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
-    }
-  }
+  if (!lin) set_dense_priority(a.ga.seg, n, ops[0].bits, ops[0].batch, block);
   if (g_experimental.decorate) g_experimental.decorate(&a);  // (measurement library: ablation bits, LDS pad, timeline buffer)
   return static_cast<int>(sqllm::launch_fused(ops[0].bits, a, static_cast<hipStream_t>(stream)));
 }

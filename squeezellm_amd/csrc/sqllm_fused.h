@@ -201,10 +201,8 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, grp = lane >> 4;
-  // Dense waves above the sparse roles' waves in the SIMD's issue arbitration, where the host asked for it (sqllm_capi.hip: a batch-1
-  // launch with sparse roles whose workgroups are all resident at once): the CSR / top-X workgroups are chains of memory round trips that
-  // finish before the dense tail anyway, and every issue slot they win is taken from an issue-bound decode.  In a multi-round launch the
-  // same priority starves the sparse workgroups that hold the slots the next dense workgroups wait for (+4-6 %): not set there.
+  // Dense waves above the sparse roles' waves in the SIMD's issue arbitration, where the host asked for it (sqllm_capi.hip:
+  // set_dense_priority -- 3-bit batch-1 launches with sparse roles whose workgroups are all resident at once).
   if (sg.gm.dense_prio) __builtin_amdgcn_s_setprio(1);
   const int ct = bid % n_col_tiles;
   const int ks = bid / n_col_tiles;

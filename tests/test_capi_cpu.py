@@ -308,32 +308,6 @@ def test_every_documented_option_round_trips():
         assert _lib.get_option(n) == before, n
 
 
-def test_sparse_workgroups_first_or_last_by_launch_size():
-    """Round 6: a batch-1 launch with sparse roles puts them FIRST in its grid (dense ids padded to a multiple of 8 behind them) when all its
-    workgroups are resident at once (4 per CU), and LAST otherwise; option sparse_last = 1 / 2 forces last / first."""
-    from squeezellm_amd import _lib
-
-    _lib.set_option("cu_count", 256)
-    try:
-        small = _lib.plan_query(4, 4096, 4096, nnz=75_000, topX=10)  # 7B o_proj: 512 dense + 74 chunks + 16 slabs
-        assert small["csr_blocks"] == 74 and small["topx_blocks"] == 16
-        assert small["grid_x"] == 96 + small["dense_blocks"] <= 1024  # sparse first: 90 -> 96, then the dense ids
-        big = _lib.plan_query(4, 11008, 4096, nnz=203_000, topX=10)  # 7B down_proj: 960 dense + 199 + 43
-        assert big["csr_blocks"] + big["topx_blocks"] + big["dense_blocks"] > 1024
-        assert big["grid_x"] == big["csr_blocks"] + big["topx_blocks"] + big["dense_blocks"]  # sparse last: no padding in front of the dense ids
-        _lib.set_option("sparse_last", 2)
-        assert _lib.plan_query(4, 11008, 4096, nnz=203_000, topX=10)["grid_x"] == (big["csr_blocks"] + big["topx_blocks"] + 7) // 8 * 8 + big["dense_blocks"]
-        _lib.set_option("sparse_last", 1)
-        assert _lib.plan_query(4, 4096, 4096, nnz=75_000, topX=10)["grid_x"] == 90 + small["dense_blocks"]
-        _lib.set_option("sparse_last", 0)
-        # batched launches keep the sparse roles first (the rule is measured at batch 1 only)
-        b2 = _lib.plan_query(4, 11008, 4096, nnz=203_000, topX=10, batch=2)
-        assert b2["grid_x"] == (b2["csr_blocks"] + b2["topx_blocks"] + 7) // 8 * 8 + b2["dense_blocks"]
-    finally:
-        _lib.set_option("sparse_last", 0)
-        _lib.set_option("cu_count", 0)
-
-
 def test_option_values_are_range_checked():
     """No option value switches the product library to anything but a documented route (`sparse_transpose = 2`
     was stored as it came and made the fused small launch read an unwritten workspace): switches take 0 / 1 only, counts
@@ -341,14 +315,14 @@ def test_option_values_are_range_checked():
     from squeezellm_amd import _lib
 
     lib = _lib.load()
-    switches = ["cols_groups", "sparse_transpose", "scratch_in_capture", "validate_csr", "mfma_split", "mfma_fuse_small",
+    switches = ["sparse_last", "cols_groups", "sparse_transpose", "scratch_in_capture", "validate_csr", "mfma_split", "mfma_fuse_small",
                 "mfma_fuse_sparse", "scratch_pool_threshold", "small_reserve_topx", "small_planes"]
     for n in switches:
         before = _lib.get_option(n)
         for bad in (2, 3, 1 << 30, -1):
             assert lib.sqllm_set_option(n.encode(), bad) == -7, (n, bad)  # SQLLM_E_OPTION
         assert _lib.get_option(n) == before, n
-    for n, top in (("sparse_last", 2), ("small_wgs_per_cu", 8), ("cu_count", 1 << 16), ("target_wgs", 1 << 24), ("groups_per_wave", 1 << 24)):
+    for n, top in (("small_wgs_per_cu", 8), ("cu_count", 1 << 16), ("target_wgs", 1 << 24), ("groups_per_wave", 1 << 24)):
         before = _lib.get_option(n)
         assert lib.sqllm_set_option(n.encode(), top + 1) == -7 and lib.sqllm_set_option(n.encode(), -1) == -7, n
         assert lib.sqllm_set_option(n.encode(), top) == 0

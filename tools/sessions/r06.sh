@@ -113,6 +113,22 @@ for l in open("gpurun_out/r06_sparse_order_tiles.txt"):
     print(d["rows"], d["set"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
 PY
   ;;
+final)
+  # the round's final tree: full GPU suite, smoke, the default bench line, and the adopted 3-bit priority rule once more (libhead.so = before it)
+  (timeout 1800 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider 2>&1 | tail -5) > gpurun_out/r06_final_tests.log
+  tail -3 gpurun_out/r06_final_tests.log
+  (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3) > gpurun_out/r06_final_smoke.log; cat gpurun_out/r06_final_smoke.log
+  cp squeezellm_amd/libsqllm_hip.so squeezellm_amd/ab/libfinal.so
+  (bash tools/ab_libs.sh "head final" "7b-w3-s45 7b-w4-s45 7b-w3-s0" 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/r06_final_ab.txt; cat gpurun_out/r06_final_ab.txt
+  (timeout 900 python bench.py 2>/dev/null | grep '^{') > gpurun_out/r06_final_bench.json
+  python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r06_final_bench.json"))
+print(d["value"], d["roofline"]["frac"], d["roofline"].get("frac_rocprof"), {k: v.get("tokens_per_s") for k, v in d["drop_in"].items() if isinstance(v, dict) and "tokens_per_s" in v})
+print({k: v.get("value") for k, v in d["sub_records"].items() if isinstance(v, dict)})
+print({k: v["ms_per_decoder_layer"] for k, v in d["sub_records"]["13b-w4-s45-batched"].items() if isinstance(v, dict) and "ms_per_decoder_layer" in v})
+PY
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
