@@ -129,6 +129,15 @@ print({k: v.get("value") for k, v in d["sub_records"].items() if isinstance(v, d
 print({k: v["ms_per_decoder_layer"] for k, v in d["sub_records"]["13b-w4-s45-batched"].items() if isinstance(v, dict) and "ms_per_decoder_layer" in v})
 PY
   ;;
+kt_w3)
+  # the 3-bit kernel trace of the standard set again, on the final tree (the set of tools/collect_profiles.sh r06 predates the dense-priority rule)
+  R=$PWD; cd /tmp && export TMPDIR=/tmp
+  (cd $R && timeout 400 python bench.py --config 7b-w3-s45 --no-cpu-baseline --no-sub-records 2>/dev/null | grep '^{' > gpurun_out/r06_bench_samebox_7b-w3-s45.json)
+  rm -rf /tmp/prof_kt_w3; timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt_w3 -o x -- python $R/bench.py --steps 20 --no-cpu-baseline --no-sub-records --config 7b-w3-s45 > /tmp/prof_kt_w3.log 2>&1
+  grep '^{' /tmp/prof_kt_w3.log > $R/gpurun_out/r06_kt_w3.bench.json
+  python $R/tools/rocprof_summary.py "$(find /tmp/prof_kt_w3 -name '*.db' | head -1)" --by-grid --match sqllm --top 12 > $R/gpurun_out/r06_kt_w3.summary.txt
+  cat $R/gpurun_out/r06_kt_w3.summary.txt; python -c "import json; d=json.load(open('$R/gpurun_out/r06_bench_samebox_7b-w3-s45.json')); print(d['value'], d['roofline']['frac'])"
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
