@@ -147,24 +147,29 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch, int
   if (g_experimental.csr_ablation_bits) gm->sparse_last |= g_experimental.csr_ablation_bits() << 1;  // (measurement library)
 }
 
-// Whose waves win the issue arbitration in a 3-BIT BATCH-1 operator launch with sparse roles (round 6; `segs` = the launch's segments as
-// make_plan left them, `total` = its workgroups): when all of them are resident at once (four 8-wave workgroups per CU) the dense
-// workgroups' waves run at s_setprio 1 (dense_role), above the CSR / top-X roles' waves -- those are chains of memory round trips that
-// finish before the dense tail anyway, and every issue slot they win is taken from an issue-bound decode.  Same-box A/Bs on two boxes
-// (profiles/r06_dense_priority_ab.txt, r06_sparse_order_ab.txt): 7B w3 s45 +2.5 / +3.5 % tokens/s (o_proj 5.1 -> 4.7-4.9 us,
-// down_proj 8.1 -> 7.4-8.0, q/k/v 8.6 -> 8.3 on one box).  NOT set:
-//  * at 4 bits: o_proj -4 % on one box, +3 % on the other, the pass +-0 / -2 %;
-//  * in launches of more workgroups than the chip holds: the low-priority sparse workgroups in front of the grid then hold the slots
-//    the next dense workgroups wait for (gate/up +5 %).  Moving them BEHIND the dense workgroups for such launches (option sparse_last
-//    per launch) was built too: -3...-9 % per launch on one box (7B / 13B gate/up, 65B: +6 % tokens/s), +3...+12 % on the other
-//    (4-bit q/k/v and down_proj, 13B: -4 % tokens/s) -- not adopted; as a global switch it costs o_proj +12 % everywhere, which
-//    is why it measured as "no change" in rounds 3 and 5.
-void set_dense_priority(sqllm::Segment* segs, int n, int bits, int batch, int total) {
-  if (bits != 3 || batch > 1 || total > 4 * cu_count() || (segs[0].gm.sparse_last & 1)) return;
-  bool sparse = false;
-  for (int i = 0; i < n; ++i) sparse = sparse || segs[i].gm.csr_blocks + segs[i].gm.topx_blocks > 0;
-  if (sparse)
-    for (int i = 0; i < n; ++i) segs[i].gm.dense_prio = 1;
+// Whose waves win the issue arbitration in a BATCH-1 operator launch with sparse roles (round 6; `segs` = the launch's segments as
+// make_plan left them, `total` = its workgroups).  The CSR / top-X workgroups are chains of memory round trips in front of the grid; the dense
+// workgroups are issue-bound.  Same-box A/Bs of variant builds, three alternating repetitions each, on two to three boxes per rule
+// (profiles/r06_dense_priority_ab.txt, r06_sparse_order_ab.txt, r06_final_ab.txt, r06_sparse_priority_ab.txt, r06_role_priority_ab.txt):
+//  1 (dense waves at s_setprio 1): 3-bit launches whose workgroups are all resident at once (four 8-wave workgroups per CU) -- the sparse
+//    workgroups finish before the dense tail anyway, and every issue slot they win is taken from the decode: 7B w3 s45 +2.1 / +2.5 / +3.5 %
+//    tokens/s (o_proj 5.1 -> 4.7-4.9 us, down_proj 8.1 -> 7.4-8.0).  In a multi-round launch the same setting starves the sparse workgroups
+//    that hold the slots the next dense workgroups wait for (gate/up +5 %), and at 4 bits it measured +-0 / -2 %.
+//  2 (sparse waves at s_setprio 1: out of the way sooner): 4-bit launches (7B w4 s45 +0.9 / +2.3 %: o_proj -4...-6 %, q/k/v -2 %; 13B +0.3 %),
+//    and 3-bit multi-round launches whose sparse workgroups alone are half a round or more (65B: q/k/v and gate/up -7 %, the pass +3.0 /
+//    +3.3 %); NOT the smaller 3-bit multi-round launches (7B gate/up +1.3 % on both boxes).
+// Built on the way and dropped: the sparse workgroups LAST in the grid per launch (-3...-9 % per launch on one box, +3...+12 % on another;
+// as a global switch it costs o_proj +12 %, which is why option sparse_last measured as "no change" in rounds 3 and 5).
+void set_role_priority(sqllm::Segment* segs, int n, int bits, int batch, int total) {
+  if (batch > 1 || (segs[0].gm.sparse_last & 1)) return;
+  int sparse = 0;
+  for (int i = 0; i < n; ++i) sparse += segs[i].gm.csr_blocks + segs[i].gm.topx_blocks;
+  if (!sparse) return;
+  const bool fits = total <= 4 * cu_count();
+  int prio = 0;
+  if (bits == 3) prio = fits ? 1 : (sparse >= 2 * cu_count() ? 2 : 0);
+  else prio = 2;
+  for (int i = 0; i < n; ++i) segs[i].gm.dense_prio = prio;
 }
 
 void fill_segment(const sqllm_op* op, sqllm::Segment* sg) {
@@ -924,7 +929,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
   }
   for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
   for (int i = n; i < sqllm::kMaxSegments; ++i) memset(&a.ga.seg[i], 0, sizeof(sqllm::Segment));
-  if (!lin) set_dense_priority(a.ga.seg, n, ops[0].bits, ops[0].batch, block);
+  if (!lin) set_role_priority(a.ga.seg, n, ops[0].bits, ops[0].batch, block);
   if (g_experimental.decorate) g_experimental.decorate(&a);  // (measurement library: ablation bits, LDS pad, timeline buffer)
   return static_cast<int>(sqllm::launch_fused(ops[0].bits, a, static_cast<hipStream_t>(stream)));
 }

@@ -203,7 +203,7 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   const int i16 = lane & 15, grp = lane >> 4;
   // Dense waves above the sparse roles' waves in the SIMD's issue arbitration, where the host asked for it (sqllm_capi.hip:
   // set_dense_priority -- 3-bit batch-1 launches with sparse roles whose workgroups are all resident at once).
-  if (sg.gm.dense_prio) __builtin_amdgcn_s_setprio(1);
+  if (sg.gm.dense_prio == 1) __builtin_amdgcn_s_setprio(1);
   const int ct = bid % n_col_tiles;
   const int ks = bid / n_col_tiles;
   const int col0 = ct * kTileN;
@@ -516,10 +516,12 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
     dense_role<BITS, BT, WAVES, ABL, XT, HALF>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, b0, nb,
                                          d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds, sg, LIN ? &sg : nullptr);
   } else if (sp >= 0 && sp < gm.csr_blocks) {
+    if (gm.dense_prio == 2) __builtin_amdgcn_s_setprio(1);  // (the sparse workgroups first out of the way: set_role_priority)
     csr_role<T, BT, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds,
                         LIN ? &sg : nullptr, gm.sparse_last >> 1, nullptr, 0, LIN ? nullptr : SQLLM_PROBE_PTR(sg));
   } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {
     // (never taken when the plan folds the top-X rows into the dense tiles)
+    if (gm.dense_prio == 2) __builtin_amdgcn_s_setprio(1);
     topx_role<T, XT, AT, false, NoGate, BT>(x, reinterpret_cast<AT*>(sg.y), sg.full_rows, sg.full_idx, gm.topX, gm.K, gm.N, b0, nb, sp - gm.csr_blocks, lds);  // (all BT rows of the pass in one go)
   }
 }

@@ -65,7 +65,7 @@ struct KernelGeom {
   int nnz, topX;
   int sparse_last;      // 1: CSR / top-X workgroups come after the dense ones in the grid
   int fold_csr;         // 1: the CSR term is walked by the dense workgroups themselves (fused small launch: csr_tile_fold_staged; csr_blocks = 0)
-  int dense_prio;       // 1: the dense workgroups' waves run at s_setprio 1, above the CSR / top-X roles' waves (batch-1 launches whose workgroups are all resident at once)
+  int dense_prio;       // issue priority inside a batch-1 launch with sparse roles (sqllm_capi.hip: set_role_priority): 1 = the dense workgroups' waves at s_setprio 1, 2 = the CSR / top-X workgroups' waves, 0 = all equal
 };
 
 constexpr int kMaxSegments = 4;   // ops one launch can cover (they share vec, K, bits, batch)

@@ -138,6 +138,17 @@ kt_w3)
   python $R/tools/rocprof_summary.py "$(find /tmp/prof_kt_w3 -name '*.db' | head -1)" --by-grid --match sqllm --top 12 > $R/gpurun_out/r06_kt_w3.summary.txt
   cat $R/gpurun_out/r06_kt_w3.summary.txt; python -c "import json; d=json.load(open('$R/gpurun_out/r06_bench_samebox_7b-w3-s45.json')); print(d['value'], d['roofline']['frac'])"
   ;;
+prio4)
+  # the opposite priority for the launches that do NOT fit the resident slots: libv8.so = libfinal.so + the CSR / top-X workgroups' waves at s_setprio 1 there
+  # (they hold slots the next dense workgroups wait for: let them finish sooner)
+  (bash tools/ab_libs.sh "final v8" "7b-w3-s45 7b-w4-s45 13b-w4-s45 65b-w3-s45" 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/r06_sparse_priority_ab.txt
+  cat gpurun_out/r06_sparse_priority_ab.txt
+  ;;
+prio5)
+  # libv9.so = libfinal.so + rule 2 of set_role_priority (sparse waves at priority 1: 4-bit launches, 3-bit multi-round launches with >= 2 x CUs sparse workgroups)
+  (bash tools/ab_libs.sh "final v9" "7b-w3-s45 7b-w4-s45 13b-w4-s45 65b-w3-s45" 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/r06_role_priority_ab.txt
+  cat gpurun_out/r06_role_priority_ab.txt | cut -c1-60
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
