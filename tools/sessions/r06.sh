@@ -149,6 +149,19 @@ prio5)
   (bash tools/ab_libs.sh "final v9" "7b-w3-s45 7b-w4-s45 13b-w4-s45 65b-w3-s45" 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/r06_role_priority_ab.txt
   cat gpurun_out/r06_role_priority_ab.txt | cut -c1-60
   ;;
+prio6)
+  # the role priority on the batch tiles too (libv10.so: set_role_priority up to 6 rows): 13B w4 s45 layer at 2-6 rows, libv9.so = the adopted batch-1-only rule; alternating
+  E=tools/experiments/small_batch_r05.py
+  for rep in 1 2 3; do for v in v9 v10; do
+    (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$v.so timeout 300 python $E --rows 2,3,4,5,6 2>&1 | grep '^{' | sed "s/^{/{\"variant\": \"$v\", /") >> gpurun_out/r06_role_priority_tiles.txt
+  done; done
+  python - <<'PY'
+import json
+for l in open("gpurun_out/r06_role_priority_tiles.txt"):
+    d = json.loads(l)
+    print(d["variant"], d["rows"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
+PY
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
