@@ -162,6 +162,27 @@ for l in open("gpurun_out/r06_role_priority_tiles.txt"):
     print(d["variant"], d["rows"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
 PY
   ;;
+final2)
+  # the final tree (role-priority rules 1 + 2): full GPU suite, kernel traces of the two s45 configs the rules touch, default bench line
+  (timeout 1800 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider 2>&1 | tail -5) > gpurun_out/r06_final2_tests.log
+  tail -3 gpurun_out/r06_final2_tests.log
+  R=$PWD; cd /tmp && export TMPDIR=/tmp
+  for c in "kt_w3 7b-w3-s45" "kt_w4s45 7b-w4-s45"; do set -- $c
+    (cd $R && timeout 400 python bench.py --config $2 --no-cpu-baseline --no-sub-records 2>/dev/null | grep '^{' > gpurun_out/r06_bench_samebox_$2.json)
+    rm -rf /tmp/prof_$1; timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_$1 -o x -- python $R/bench.py --steps 20 --no-cpu-baseline --no-sub-records --config $2 > /tmp/prof_$1.log 2>&1
+    grep '^{' /tmp/prof_$1.log > $R/gpurun_out/r06_$1.bench.json
+    python $R/tools/rocprof_summary.py "$(find /tmp/prof_$1 -name '*.db' | head -1)" --by-grid --match sqllm --top 12 > $R/gpurun_out/r06_$1.summary.txt
+    cat $R/gpurun_out/r06_$1.summary.txt; python -c "import json; d=json.load(open('$R/gpurun_out/r06_bench_samebox_$2.json')); print('$2 un-profiled on this box:', d['value'], d['roofline']['frac'])"
+  done
+  cd $R
+  (timeout 900 python bench.py 2>/dev/null | grep '^{') > gpurun_out/r06_final2_bench.json
+  python -c "
+import json
+d = json.load(open('gpurun_out/r06_final2_bench.json'))
+print(d['value'], d['roofline']['frac'], d['roofline'].get('frac_rocprof'), {k: v.get('value') for k, v in d['sub_records'].items() if isinstance(v, dict)})
+print({k: v['ms_per_decoder_layer'] for k, v in d['sub_records']['13b-w4-s45-batched'].items() if isinstance(v, dict) and 'ms_per_decoder_layer' in v})
+"
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
