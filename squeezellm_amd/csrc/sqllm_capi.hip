@@ -122,7 +122,12 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch, int
       // (profiles/r03_target_wgs_groups_batch1.txt)
       const double mb = (double)op->K * op->N * op->bits / 8.0 / 1e6;
       const bool alone = ops_in_launch <= 1;
-      target = (mb <= 12.0 ? (alone ? 2 : 1) : (!alone && mb <= 16.0) ? 2 : (alone ? 4 : 3)) * cu_count();
+      // ... and the DENSE-ONLY 3-bit 7B gate/up pair, 16.9 MB each: two per CU and op = 688 workgroups of two K slices per tile, one
+      // resident round, 10.7 us against 11.0 for three per CU (1376 workgroups); at 4 bits the same cut loses, and with sparse roles in the
+      // grid it is 1 % slower (profiles/r06_group_geometry.txt, r06_w3_gateup_geometry_ab.txt)
+      const bool dense_only = !(op->rows && op->nnz > 0) && !(op->full_rows && op->topX > 0);
+      const double two_per_cu_mb = (op->bits == 3 && dense_only) ? 18.0 : 16.0;
+      target = (mb <= 12.0 ? (alone ? 2 : 1) : (!alone && mb <= two_per_cu_mb) ? 2 : (alone ? 4 : 3)) * cu_count();
       if (waves > sqllm::kWaves) target = target * sqllm::kWaves / waves;  // (16-wave workgroups: half as many, twice the rows each)
     }
     int slices = (target + gm->col_tiles / 2) / gm->col_tiles;

@@ -183,6 +183,17 @@ print(d['value'], d['roofline']['frac'], d['roofline'].get('frac_rocprof'), {k: 
 print({k: v['ms_per_decoder_layer'] for k, v in d['sub_records']['13b-w4-s45-batched'].items() if isinstance(v, dict) and 'ms_per_decoder_layer' in v})
 "
   ;;
+geometry_groups)
+  # the q/k/v and gate/up GROUP launches under explicit per-op workgroup counts (tools/experiments/small_op_geometry.py --groups)
+  (timeout 900 python tools/experiments/small_op_geometry.py --groups --bits 4 2>&1 | grep '^{') > gpurun_out/r06_group_geometry.txt
+  (timeout 900 python tools/experiments/small_op_geometry.py --groups --bits 3 2>&1 | grep '^{') >> gpurun_out/r06_group_geometry.txt
+  cat gpurun_out/r06_group_geometry.txt
+  ;;
+geom3)
+  # libv11.so = libv9.so + two workgroups per CU and op for the 3-bit 7B gate/up pair (make_plan)
+  (bash tools/ab_libs.sh "v9 v11" "7b-w3-s0 7b-w3-s45" 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/r06_w3_gateup_geometry_ab.txt
+  cat gpurun_out/r06_w3_gateup_geometry_ab.txt
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
