@@ -194,6 +194,20 @@ geom3)
   (bash tools/ab_libs.sh "v9 v11" "7b-w3-s0 7b-w3-s45" 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/r06_w3_gateup_geometry_ab.txt
   cat gpurun_out/r06_w3_gateup_geometry_ab.txt
   ;;
+final3)
+  # last check of the round's tree: the driver's own sequence -- GPU suite with -x, smoke, default bench line
+  (timeout 1800 python -m pytest tests -x -q -m gpu -p no:cacheprovider 2>&1 | tail -4) > gpurun_out/r06_final3_tests.log; tail -2 gpurun_out/r06_final3_tests.log
+  (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2) > gpurun_out/r06_final3_smoke.log; cat gpurun_out/r06_final3_smoke.log
+  (timeout 900 python bench.py 2>/dev/null | grep '^{') > gpurun_out/r06_final3_bench.json
+  python -c "
+import json
+d = json.load(open('gpurun_out/r06_final3_bench.json'))
+print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('frac_rocprof'), d['cpu_baseline']['value'])
+print({k: v.get('value') for k, v in d['sub_records'].items() if isinstance(v, dict)})
+print({k: v['ms_per_decoder_layer'] for k, v in d['sub_records']['13b-w4-s45-batched'].items() if isinstance(v, dict) and 'ms_per_decoder_layer' in v})
+print({k: v.get('tokens_per_s') for k, v in d['drop_in'].items() if isinstance(v, dict) and 'tokens_per_s' in v})
+"
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
