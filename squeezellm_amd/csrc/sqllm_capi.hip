@@ -353,7 +353,7 @@ bool takes_small_split(const sqllm_op* op, int n_ops = 1) {
 // workgroup -- table build, decode, combine -- hide behind its neighbours').
 void make_plan_cols(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch = 1) {
   make_plan(op, gm, 1);
-  const int bt = sqllm::batch_tile(gm->batch);
+  const int bt = sqllm::batch_tile_op(gm->batch);
   const int grid_y = (gm->batch + bt - 1) / bt;
   const long long total_units = (long long)gm->col_tiles * gm->units_total;
   long long upw = (long long)knobs().groups_per_wave.load(std::memory_order_relaxed) * sqllm::kWaves;
@@ -406,9 +406,6 @@ bool cols_pays(const sqllm_op* op, int n_ops) {
   if (knobs().cols_min_batch.load(std::memory_order_relaxed) > 0 || knobs().cols_max_batch.load(std::memory_order_relaxed) > 0) return true;
   const double mb = (double)op->K * op->N * op->bits / 8e6;  // (of a group: the sum of its ops)
   if (op->bits == 4) return n_ops >= 3 || (n_ops == 1 && mb >= 20.0);
-  // (3-bit, round 6: at exactly 3 / 5 rows the batch tiles of that many rows beat the column-lane kernel, which serves them in its
-  // 4- / 8-row passes -- same box, 13B s45 layer 84 -> 78 / 120 -> 107 us: profiles/r06_small_batch_w3_tiles_vs_cols.txt)
-  if (op->batch == 3 || op->batch == 5) return false;
   if (op->batch <= 4 && mb >= 16.0) return true;
   return op->N >= 8192;
 }
@@ -555,7 +552,7 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   plan->csr_blocks = gm.csr_blocks;
   plan->topx_blocks = gm.topx_blocks;
   plan->grid_x = (mfma && !small_split) ? gm.dense_blocks : gm.dense_block0 + gm.dense_blocks;  // (wide batches: the sparse terms are a launch of their own)
-  const int rows_per_pass = wide ? (gm.batch > 0 ? gm.batch : 1) : mfma ? 16 * (row_blocks ? row_blocks : sqllm::mfma_row_blocks(gm.batch)) : cols ? sqllm::batch_tile(gm.batch) : sqllm::batch_tile_op(gm.batch);
+  const int rows_per_pass = wide ? (gm.batch > 0 ? gm.batch : 1) : mfma ? 16 * (row_blocks ? row_blocks : sqllm::mfma_row_blocks(gm.batch)) : sqllm::batch_tile_op(gm.batch);
   plan->grid_y = (gm.batch + rows_per_pass - 1) / rows_per_pass;
   return SQLLM_OK;
 }

@@ -742,10 +742,14 @@ static hipError_t launch_cols_inst(const LaunchArgs& a, hipStream_t stream) {
 
 template <int BITS>
 static hipError_t launch_cols_bits(const LaunchArgs& a, hipStream_t stream) {
-  switch (batch_tile(a.ga.seg[0].gm.batch)) {
+  switch (batch_tile_op(a.ga.seg[0].gm.batch)) {  // (passes of exactly 3 / 5 / 6 rows too: round 6)
     case 1: return launch_cols_inst<BITS, 1>(a, stream);
     case 2: return launch_cols_inst<BITS, 2>(a, stream);
+    case 3: return launch_cols_inst<BITS, 3>(a, stream);
     case 4: return launch_cols_inst<BITS, 4>(a, stream);
+    case 5: return launch_cols_inst<BITS, 5>(a, stream);
+    case 6: return launch_cols_inst<BITS, 6>(a, stream);
+    case 7: return launch_cols_inst<BITS, 7>(a, stream);
     default: return launch_cols_inst<BITS, 8>(a, stream);
   }
 }

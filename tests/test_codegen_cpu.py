@@ -143,7 +143,7 @@ def test_column_lane_kernels(asm):
     with an SGPR offset (the compiler's own pointer arithmetic once cost two v_readlane per load), no
     FLAT, no scratch, <= 80 VGPRs (three 8-wave workgroups per CU)."""
     ks = _family(asm, "_ZN5sqllm16sqllm_fused_cols")
-    assert len(ks) == 8  # {3,4} bits x batch tile {1,2,4,8}
+    assert len(ks) == 16  # {3,4} bits x rows per pass {1,2,3,4,5,6,7,8}
     for name, body in ks.items():
         assert not [l for l in body if re.match(r"\s+flat_", l)], name
         pk = [l for l in body if re.match(r"\s+v_pk_fma_f32", l)]

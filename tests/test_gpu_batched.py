@@ -317,7 +317,7 @@ def test_column_lane_kernel_vs_oracle(qc, gpu, bits, kind, shape):
     t = H.to_torch(case, gpu)
     try:
         _routing(1 << 30, 1, 1 << 30)
-        for B in (1, 2, 3, 4, 5, 7, 8, 9, 16, 23):
+        for B in (1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 14, 15, 16, 23):  # passes of every width 1..8, alone and behind an 8-row pass
             rng = np.random.default_rng(B)
             x = rng.normal(size=(B, K)).astype(np.float32)
             mul = rng.normal(size=(B, N)).astype(np.float32)
@@ -377,7 +377,7 @@ def test_column_lane_kernel_runs_groups(gpu, bits, kind):
                          cols=t.get("cols"), vals=t.get("vals"), full_rows=t.get("full_rows"), full_row_indices=t.get("full_row_indices")))
     try:
         _routing(1 << 30, 1, 1 << 30)
-        for B in (1, 2, 3, 4, 8, 9, 16):
+        for B in (1, 2, 3, 4, 5, 6, 7, 8, 9, 16):
             rng = np.random.default_rng(B)
             x = rng.normal(size=(B, K)).astype(np.float32)
             xt = torch.from_numpy(x).to(gpu)

@@ -208,6 +208,42 @@ print({k: v['ms_per_decoder_layer'] for k, v in d['sub_records']['13b-w4-s45-bat
 print({k: v.get('tokens_per_s') for k, v in d['drop_in'].items() if isinstance(v, dict) and 'tokens_per_s' in v})
 "
   ;;
+cols356)
+  # passes of exactly 3 / 5 / 6 rows in the COLUMN-LANE kernel too: libv9.so = before (4- / 8-row passes), libv12.so = with them and the 3-bit "3 / 5 rows -> tiles" rule,
+  # libv13.so = with them and without that rule; 13B s45 layer, parity of the new instantiations first
+  (timeout 900 python -m pytest tests/test_gpu_batched.py -m gpu -q -p no:cacheprovider -k "column_lane or three_batched or small_shapes or test_batch_tiles" 2>&1 | tail -2) > gpurun_out/r06_cols356_tests.log; cat gpurun_out/r06_cols356_tests.log
+  E=tools/experiments/small_batch_r05.py
+  for rep in 1 2; do for v in v9 v12 v13; do
+    (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$v.so timeout 300 python $E --rows 2,3,4 2>&1 | grep '^{' | sed "s/^{/{\"variant\": \"$v\", /") >> gpurun_out/r06_cols356_w4.txt
+    (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$v.so timeout 300 python $E --bits 3 --rows 3,5,6,7,8 2>&1 | grep '^{' | sed "s/^{/{\"variant\": \"$v\", /") >> gpurun_out/r06_cols356_w3.txt
+  done; done
+  python - <<'PY'
+import json
+for f in ("gpurun_out/r06_cols356_w4.txt", "gpurun_out/r06_cols356_w3.txt"):
+    print(f)
+    for l in open(f):
+        d = json.loads(l)
+        print(d["variant"], d["rows"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
+PY
+  ;;
+cols56)
+  # libv13b.so = this tree (column-lane passes of exactly 3 / 5 / 6 / 7 rows; 4-bit column-lane kernel up to 4 rows), libv14.so = the same with the 4-bit column-lane
+  # kernel up to 6 rows (three-op groups and single ops >= 20 MB), libv9.so = before the exact passes; 13B s45 layer
+  E=tools/experiments/small_batch_r05.py
+  (timeout 600 python -m pytest tests/test_gpu_batched.py -m gpu -q -p no:cacheprovider -k "column_lane or three_batched" 2>&1 | tail -2)
+  for rep in 1 2; do for v in v9 v13b v14; do
+    (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$v.so timeout 300 python $E --rows 3,5,6 2>&1 | grep '^{' | sed "s/^{/{\"variant\": \"$v\", /") >> gpurun_out/r06_cols56_w4.txt
+    (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$v.so timeout 300 python $E --bits 3 --rows 3,5,6,7 2>&1 | grep '^{' | sed "s/^{/{\"variant\": \"$v\", /") >> gpurun_out/r06_cols56_w3.txt
+  done; done
+  python - <<'PY'
+import json
+for f in ("gpurun_out/r06_cols56_w4.txt", "gpurun_out/r06_cols56_w3.txt"):
+    print(f)
+    for l in open(f):
+        d = json.loads(l)
+        print(d["variant"], d["rows"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
+PY
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
