@@ -335,7 +335,10 @@ int mfma_min_batch_of(const sqllm_op* op, int n_ops = 1) {
 }
 int cols_max_batch_of(const sqllm_op* op) {
   const int v = knobs().cols_max_batch.load(std::memory_order_relaxed);
-  return v > 0 ? v : (op->bits == 3 ? 16 : 4);
+  // 4-bit: up to 4 rows; single ops of >= 20 MB up to 6 (round 6, with the kernel's passes of exactly 5 / 6 rows: 13B down_proj 22.4 / 25.7 us against
+  // 23.6 / 26.7 on the 5- / 6-row tiles, the layer -0.8 / -1.9 %; at 7 rows its 7-row pass beats the fused small launch by events, 29.6 against
+  // 32.5 us, and loses by graph wall, the layer +1.1 %: profiles/r06_cols_single_ops_5_7.txt; groups are kept at 4 rows by cols_pays)
+  return v > 0 ? v : (op->bits == 3 ? 16 : ((double)op->K * op->N / 2e6 >= 20.0 ? 6 : 4));
 }
 
 bool takes_mfma_path(const sqllm_op* op, int n_ops = 1) { return op->batch >= 1 && op->batch >= mfma_min_batch_of(op, n_ops); }
@@ -405,7 +408,7 @@ int cols_min_batch_of() {
 bool cols_pays(const sqllm_op* op, int n_ops) {
   if (knobs().cols_min_batch.load(std::memory_order_relaxed) > 0 || knobs().cols_max_batch.load(std::memory_order_relaxed) > 0) return true;
   const double mb = (double)op->K * op->N * op->bits / 8e6;  // (of a group: the sum of its ops)
-  if (op->bits == 4) return n_ops >= 3 || (n_ops == 1 && mb >= 20.0);
+  if (op->bits == 4) return (n_ops >= 3 && op->batch <= 4) || (n_ops == 1 && mb >= 20.0);
   if (op->batch <= 4 && mb >= 16.0) return true;
   return op->N >= 8192;
 }

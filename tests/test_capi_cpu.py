@@ -100,7 +100,9 @@ def test_plan_geometry():
         pt = _lib.plan_query(4, 4096, 4096, batch=b)
         assert pt["grid_y"] == 1 and pt["dense_blocks"] == pt["col_tiles"] * pt["k_slices"], (b, pt)
     assert _lib.plan_query(4, 4096, 4096, batch=8)["dense_blocks"] == 64 * _lib.plan_query(4, 4096, 4096, batch=8)["k_slices"]  # 8.4 MB alone: 8-row tile
-    assert _lib.plan_query(4, 4096, 11008, batch=6)["dense_blocks"] == 172 * _lib.plan_query(4, 4096, 11008, batch=6)["k_slices"]  # 6 rows: tiles whatever the size
+    assert _lib.plan_query(4, 4096, 8192, batch=6)["dense_blocks"] == 128 * _lib.plan_query(4, 4096, 8192, batch=6)["k_slices"]  # 6 rows, 16.8 MB: the 6-row tile
+    # (a single op of >= 20 MB takes the column-lane kernel up to 6 rows: ranges of the flattened (tile, unit) space, three workgroups per CU)
+    assert _lib.plan_query(4, 4096, 11008, batch=6)["grid_y"] == 1 and _lib.plan_query(4, 4096, 11008, batch=6)["dense_blocks"] <= 3 * 256
     assert _lib.plan_query(3, 4096, 4096, batch=17)["grid_y"] == 1
     assert _lib.plan_query(4, 4096, 4096, batch=9)["grid_y"] == 1
     assert _lib.plan_query(4, 4096, 4096, batch=33)["grid_y"] == 1

@@ -244,6 +244,19 @@ for f in ("gpurun_out/r06_cols56_w4.txt", "gpurun_out/r06_cols56_w3.txt"):
         print(d["variant"], d["rows"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
 PY
   ;;
+cols_single)
+  # libv15.so = this tree (4-bit single ops >= 20 MB on the column-lane kernel up to 7 rows) against libv13b.so (up to 4 rows); 13B w4 s45 layer at 5-8 rows
+  E=tools/experiments/small_batch_r05.py
+  for rep in 1 2 3; do for v in v13b v15; do
+    (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$v.so timeout 300 python $E --rows 5,6,7,8 2>&1 | grep '^{' | sed "s/^{/{\"variant\": \"$v\", /") >> gpurun_out/r06_cols_single_ops_5_7.txt
+  done; done
+  python - <<'PY'
+import json
+for l in open("gpurun_out/r06_cols_single_ops_5_7.txt"):
+    d = json.loads(l)
+    print(d["variant"], d["rows"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
+PY
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
