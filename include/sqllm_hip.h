@@ -296,8 +296,8 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     measured default, which depends on the bit width; get_option returns the stored 0): 4-bit 2..4 / 7
  *                     (9 for an op of <= 16 MB of packed weights alone in its launch), 3-bit 2..8 / 9.
  *                     With the two cols_* options at their defaults the column-lane kernel is further reserved
- *                     for what it measured faster on: 4-bit, groups of three or more ops and single ops of
- *                     >= 20 MB packed weights; 3-bit, >= 16 MB at up to 4 rows or N >= 8192; setting either option
+ *                     for what it measured faster on: 4-bit, groups of three or more ops (up to 4 rows) and single ops of
+ *                     >= 20 MB packed weights (up to 6 rows); 3-bit, >= 16 MB at up to 4 rows or N >= 8192; setting either option
  *                     takes the range at its word.
  *   "cols_groups"     1 (default): a GROUP of ops over one vec (sqllm_launch_group) may take the column-lane kernel
  *                     too, as one launch, judged by the sum of its columns; 0: groups stay on the batch tiles
