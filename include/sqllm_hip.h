@@ -292,7 +292,7 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     routing of the *_batched operators by batch size: cols_min_batch .. cols_max_batch
  *                     rows run on the column-lane kernel (lane = output column, vec in SGPRs),
  *                     mfma_min_batch rows and more on the matrix cores, everything else on the
- *                     batch tiles of the batch-1 kernel (tiles of exactly 1, 2, 3, 4, 5, 6 or 8 rows).  Defaults (value 0 =
+ *                     batch tiles of the batch-1 kernel (tiles of exactly 1..8 rows).  Defaults (value 0 =
  *                     measured default, which depends on the bit width; get_option returns the stored 0): 4-bit 2..4 / 7
  *                     (9 for an op of <= 16 MB of packed weights alone in its launch), 3-bit 2..8 / 9.
  *                     With the two cols_* options at their defaults the column-lane kernel is further reserved

@@ -148,8 +148,7 @@ struct StreamArgs {
 // batch rows handled per weight pass for a given batch size (template instantiations 1/2/4/8)
 inline int batch_tile(int batch) { return batch <= 1 ? 1 : batch == 2 ? 2 : batch <= 4 ? 4 : 8; }
 // ... of the fused batch-tile kernel behind the OPERATOR names (sqllm_fused_matvec<BITS, BT>, not the fused linear): a tile
-// of exactly 3, 5 or 6 rows too -- a 5-row batch on the 8-row tile pays the broadcasts and FMAs of 8 (round 6) -- and of the column-lane kernel
-// (7: the column-lane kernel only; the batch tiles serve 7 rows on their 8-row instantiation)
+// of exactly 3, 5, 6 or 7 rows too -- a 5-row batch on the 8-row tile pays the broadcasts and FMAs of 8 (round 6) -- and of the column-lane kernel
 inline int batch_tile_op(int batch) { return (batch == 3 || batch == 5 || batch == 6 || batch == 7) ? batch : batch_tile(batch); }
 
 // blocks of 16 batch rows one pass of the wide-batch (matrix-core) kernel covers: 1, 2 or 4

@@ -694,10 +694,11 @@ template <int BITS, bool LIN>
 static hipError_t launch_bt(const LaunchArgs& a, hipStream_t stream) {
   const int batch = a.ga.seg[0].gm.batch;
   if constexpr (!LIN) {
-    switch (batch_tile_op(batch)) {  // (operator launches: tiles of exactly 3 / 5 / 6 rows too)
+    switch (batch_tile_op(batch)) {  // (operator launches: tiles of exactly 3 / 5 / 6 / 7 rows too)
       case 3: return launch_inst<BITS, 3, kWaves, 0, LIN>(a, stream);
       case 5: return launch_inst<BITS, 5, kWaves, 0, LIN>(a, stream);
       case 6: return launch_inst<BITS, 6, kWaves, 0, LIN>(a, stream);
+      case 7: return launch_inst<BITS, 7, kWaves, 0, LIN>(a, stream);
       default: break;
     }
   }

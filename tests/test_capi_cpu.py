@@ -96,7 +96,7 @@ def test_plan_geometry():
     # kernel: passes of 16 / 32 / 64 rows; below, batch tiles of exactly 1, 2, 3, 4, 5, 6 or 8 rows (round 6: 3, 5, 6)
     assert _lib.get_option("mfma_min_batch") == 0  # = the measured default
     assert _lib.plan_query(4, 4096, 11008, batch=8)["grid_y"] == 1 and _lib.plan_query(3, 4096, 4096, batch=16)["grid_y"] == 1  # (3-bit: matrix cores from 9 rows since round 4)
-    for b, tiles in ((3, 3), (5, 5), (6, 6), (7, 8)):  # (batch, rows per pass) on the batch tiles: one pass, K slices per column tile
+    for b, tiles in ((3, 3), (5, 5), (6, 6), (7, 7)):  # (batch, rows per pass) on the batch tiles: one pass, K slices per column tile
         pt = _lib.plan_query(4, 4096, 4096, batch=b)
         assert pt["grid_y"] == 1 and pt["dense_blocks"] == pt["col_tiles"] * pt["k_slices"], (b, pt)
     assert _lib.plan_query(4, 4096, 4096, batch=8)["dense_blocks"] == 64 * _lib.plan_query(4, 4096, 4096, batch=8)["k_slices"]  # 8.4 MB alone: 8-row tile

@@ -257,6 +257,21 @@ for l in open("gpurun_out/r06_cols_single_ops_5_7.txt"):
     print(d["variant"], d["rows"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
 PY
   ;;
+tile7)
+  # the 7-row batch tile (libv16.so) against the tree before it (libprev.so: 7 rows on the 8-row tile): parity, then the 13B s45 layer at 7 rows, 4-bit and 3-bit
+  (timeout 600 python -m pytest tests/test_gpu_batched.py -m gpu -q -p no:cacheprovider -k "test_batch_tiles_every_row_count or three_batched" 2>&1 | tail -1)
+  E=tools/experiments/small_batch_r05.py
+  for rep in 1 2 3; do for v in prev v16; do
+    (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$v.so timeout 300 python $E --rows 7 2>&1 | grep '^{' | sed "s/^{/{\"variant\": \"$v\", /") >> gpurun_out/r06_tile7.txt
+    (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$v.so timeout 300 python $E --bits 3 --rows 7 2>&1 | grep '^{' | sed "s/^{/{\"variant\": \"$v\", /") >> gpurun_out/r06_tile7.txt
+  done; done
+  python - <<'PY'
+import json
+for l in open("gpurun_out/r06_tile7.txt"):
+    d = json.loads(l)
+    print(d["variant"], d["config"], d["rows"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
+PY
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
