@@ -272,6 +272,11 @@ for l in open("gpurun_out/r06_tile7.txt"):
     print(d["variant"], d["config"], d["rows"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
 PY
   ;;
+loadprio)
+  # dense waves at s_setprio 2 while they ISSUE loads (v17: the first chunk only; v18: every chunk), back to the role's priority for the decode; libhead.so = this tree
+  (bash tools/ab_libs.sh "head v17 v18" "7b-w4-s0 7b-w3-s45 7b-w4-s45 13b-w4-s45" 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/r06_load_phase_priority_ab.txt
+  cat gpurun_out/r06_load_phase_priority_ab.txt
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
