@@ -277,6 +277,12 @@ loadprio)
   (bash tools/ab_libs.sh "head v17 v18" "7b-w4-s0 7b-w3-s45 7b-w4-s45 13b-w4-s45" 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/r06_load_phase_priority_ab.txt
   cat gpurun_out/r06_load_phase_priority_ab.txt
   ;;
+chunks)
+  # the sparse roles' granularity again, now that their waves have a priority of their own: CSR chunk 1024 (product) / 2048 non-zeros, top-X slab 256 (product) / 512 / 128 k's
+  # (builds of the product sources with the measurement switches: -DSQLLM_ABLATION_BUILD -DSQLLM_CSR_CHUNK=... / -DSQLLM_TOPX_ROWS=...)
+  (bash tools/ab_libs.sh "c1024 c2048 t512 t128" "7b-w4-s45 7b-w3-s45 13b-w4-s45" 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/r06_sparse_granularity_ab.txt
+  cat gpurun_out/r06_sparse_granularity_ab.txt | cut -c1-60
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
