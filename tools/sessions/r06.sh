@@ -1,6 +1,9 @@
 #!/bin/bash
 # Round 6: every gpurun session of the round, replayable -- gpurun --timeout 1500 -- 'bash tools/sessions/r06.sh s1'
 # (run from the repo root; results land in gpurun_out/, the ones quoted in DESIGN.md / LABNOTES.md were copied to profiles/r06_*).
+# Variant libraries the A/B sessions load (squeezellm_amd/ab/lib<name>.so, git-ignored, not kept): libr05.so = the round-5 tree (git worktree at 87e8bf2,
+# python -m squeezellm_amd.build); libhead.so / libfinal.so / libprev.so = the tree of the moment before the change under test; libv<N>.so = a copy of csrc/
+# with the one-line patch the session's comment and LABNOTES.md (round 6, sections 4-5) describe, compiled with the flags of squeezellm_amd/build.py.
 mkdir -p gpurun_out
 case "$1" in
 s1)
