@@ -87,12 +87,20 @@ def test_llama7b_decoder_layer_grouped(gpu, bits, sparse, topX):
     _check_layer(layers, gpu, batch=0, graph=True)
 
 
-@pytest.mark.parametrize("batch", [1, 2, 4, 8, 12, 16])
+@pytest.mark.parametrize("batch", [1, 2, 3, 4, 5, 6, 7, 8, 12, 16])
 def test_llama13b_decoder_layer_grouped_batched(gpu, batch):
-    """BASELINE configs[3]: 13B shapes, w4 s45, the *_batched operators at 1 / 2 / 4 / 8 rows, grouped
-    (q/k/v and gate/up groups stay one launch of the batch tiles; o_proj / down_proj alone take the
-    router's kernel for that batch size)."""
+    """BASELINE configs[3]: 13B shapes, w4 s45, the *_batched operators at every row count of "batch 1..8" and beyond, grouped, by
+    the default routing: batch tiles of exactly that many rows / column-lane passes up to 6 rows, the fused small launch from 7
+    (o_proj alone on the 7- / 8-row tile)."""
     layers = _decoder_layer("llama-13b", 4, 0.0045, 10, gpu, seed0=1300)
+    _check_layer(layers, gpu, batch=batch, graph=False)
+
+
+@pytest.mark.parametrize("batch", [3, 5, 7])
+def test_llama13b_decoder_layer_w3_odd_rows(gpu, batch):
+    """3-bit 13B layer at 3 / 5 / 7 rows: the column-lane kernel's passes of exactly that many rows (q/k/v group, gate/up, down_proj)
+    and the batch tile of that width (o_proj), grouped, against the C oracle."""
+    layers = _decoder_layer("llama-13b", 3, 0.0045, 10, gpu, seed0=1360)
     _check_layer(layers, gpu, batch=batch, graph=False)
 
 
