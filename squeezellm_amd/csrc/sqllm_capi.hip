@@ -165,16 +165,40 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch, int
 //    +3.3 %); NOT the smaller 3-bit multi-round launches (7B gate/up +1.3 % on both boxes).
 // Built on the way and dropped: the sparse workgroups LAST in the grid per launch (-3...-9 % per launch on one box, +3...+12 % on another;
 // as a global switch it costs o_proj +12 %, which is why option sparse_last measured as "no change" in rounds 3 and 5).
-void set_role_priority(sqllm::Segment* segs, int n, int bits, int batch, int total) {
+void set_role_priority(sqllm::Segment* segs, int n, int bits, int batch, int total, bool widened) {
   if (batch > 1 || (segs[0].gm.sparse_last & 1)) return;
   int sparse = 0;
-  for (int i = 0; i < n; ++i) sparse += segs[i].gm.csr_blocks + segs[i].gm.topx_blocks;
+  for (int i = 0; i < n; ++i) sparse += (segs[i].gm.csr_wide ? 2 : 1) * segs[i].gm.csr_blocks + segs[i].gm.topx_blocks;  // (counted in chunks of kCsrChunk)
   if (!sparse) return;
-  const bool fits = total <= 4 * cu_count();
+  const bool fits = !widened && total <= 4 * cu_count();
   int prio = 0;
   if (bits == 3) prio = fits ? 1 : (sparse >= 2 * cu_count() ? 2 : 0);
   else prio = 2;
   for (int i = 0; i < n; ++i) segs[i].gm.dense_prio = prio;
+}
+
+// CSR chunks of 2 * kCsrChunk non-zeros in BATCH-1 operator launches that exceed the resident slots AND carry many sparse workgroups (>= 1.25 x
+// CUs at kCsrChunk each): half as many workgroups in front of the grid, each with twice the non-zeros in the same chain of round trips.  A build with
+// 2048 everywhere (profiles/r06_sparse_granularity_ab.txt) showed both sides: gate/up -2.7...-6.4 % (7B 430 / 13B 702 sparse workgroups), 13B
+// down_proj -5.7 % (365), 13B q/k/v -3 % (408), against o_proj +13...+29 % (its fewer, longer sparse workgroups become the launch's tail), 7B q/k/v
+// +1-1.5 % (270) and the 7B 3-bit down_proj +13 % (fits: dense priority).  Returns true if it widened; `*total` is recomputed then.
+bool widen_csr_chunks(sqllm::Segment* segs, int n, int batch, int* total) {
+  if (batch > 1 || *total <= 4 * cu_count() || (segs[0].gm.sparse_last & 1)) return false;
+  int sparse = 0;
+  for (int i = 0; i < n; ++i) sparse += segs[i].gm.csr_blocks + segs[i].gm.topx_blocks;
+  if (4 * sparse < 5 * cu_count()) return false;
+  int t = 0;
+  for (int i = 0; i < n; ++i) {
+    sqllm::KernelGeom& gm = segs[i].gm;
+    if (gm.csr_blocks > 0) {
+      gm.csr_wide = 1;
+      gm.csr_blocks = (gm.nnz + 2 * sqllm::kCsrChunk - 1) / (2 * sqllm::kCsrChunk);
+      gm.dense_block0 = (gm.csr_blocks + gm.topx_blocks + 7) / 8 * 8;
+    }
+    t += (gm.dense_block0 + gm.dense_blocks + 7) / 8 * 8;
+  }
+  *total = t;
+  return true;
 }
 
 void fill_segment(const sqllm_op* op, sqllm::Segment* sg) {
@@ -538,7 +562,14 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
   }
   const bool cols = !mfma && takes_cols_path(op);
   if (cols) make_plan_cols(op, &gm);
-  else if (!mfma) make_plan(op, &gm);
+  else if (!mfma) {
+    make_plan(op, &gm);
+    sqllm::Segment one;  // (as launched alone: a batch-1 launch that exceeds the resident slots may take wide CSR chunks)
+    one.gm = gm;
+    int total = (gm.dense_block0 + gm.dense_blocks + 7) / 8 * 8;
+    (void)widen_csr_chunks(&one, 1, op->batch, &total);
+    gm = one.gm;
+  }
   const bool small_split = mfma && !wide && takes_small_split(op);
   if (small_split) {  // the fused small launch: CSR term folded into the dense workgroups, top-X slabs in the grid
     // (as launched with a workspace: vec transposed, 8-16 top-X workgroups, the dense ranges planned beside them)
@@ -934,7 +965,18 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
   }
   for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
   for (int i = n; i < sqllm::kMaxSegments; ++i) memset(&a.ga.seg[i], 0, sizeof(sqllm::Segment));
-  if (!lin) set_role_priority(a.ga.seg, n, ops[0].bits, ops[0].batch, block);
+  if (!lin) {
+    const bool widened = widen_csr_chunks(a.ga.seg, n, ops[0].batch, &block);
+    if (widened) {
+      int at = 0;
+      for (int i = 0; i < n; ++i) {
+        a.ga.block0[i] = at;
+        at += (a.ga.seg[i].gm.dense_block0 + a.ga.seg[i].gm.dense_blocks + 7) / 8 * 8;
+      }
+      for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = at;
+    }
+    set_role_priority(a.ga.seg, n, ops[0].bits, ops[0].batch, block, widened);
+  }
   if (g_experimental.decorate) g_experimental.decorate(&a);  // (measurement library: ablation bits, LDS pad, timeline buffer)
   return static_cast<int>(sqllm::launch_fused(ops[0].bits, a, static_cast<hipStream_t>(stream)));
 }

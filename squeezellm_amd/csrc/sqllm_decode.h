@@ -548,6 +548,6 @@ __device__ __forceinline__ float ld_x(const XT* p) {
   "s"(sg.bias), "s"(sg.out16), "s"(sg.gm.K), "s"(sg.gm.N), "s"(sg.gm.batch), "s"(sg.gm.col_tiles),                     \
   "s"(sg.gm.units_total), "s"(sg.gm.units_per_wg), "s"(sg.gm.k_slices), "s"(sg.gm.dense_blocks),                       \
   "s"(sg.gm.dense_block0), "s"(sg.gm.csr_blocks), "s"(sg.gm.topx_blocks), "s"(sg.gm.nnz), "s"(sg.gm.topX),             \
-  "s"(sg.gm.sparse_last), "s"(sg.gm.dense_prio)
+  "s"(sg.gm.sparse_last), "s"(sg.gm.dense_prio), "s"(sg.gm.csr_wide)
 
 }  // namespace sqllm

@@ -517,6 +517,13 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
                                          d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds, sg, LIN ? &sg : nullptr);
   } else if (sp >= 0 && sp < gm.csr_blocks) {
     if (gm.dense_prio == 2) __builtin_amdgcn_s_setprio(1);  // (the sparse workgroups first out of the way: set_role_priority)
+    if constexpr (BT == 1 && !LIN) {
+      if (gm.csr_wide) {  // (half as many, twice as deep: widen_csr_chunks)
+        csr_role<T, BT, XT, AT, false, false, NoGate, 2 * kCsrChunk>(x, reinterpret_cast<AT*>(sg.y), sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds,
+                                                                     nullptr, gm.sparse_last >> 1, nullptr, 0, SQLLM_PROBE_PTR(sg));
+        return;
+      }
+    }
     csr_role<T, BT, XT, AT>(x, reinterpret_cast<AT*>(sg.y), sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds,
                         LIN ? &sg : nullptr, gm.sparse_last >> 1, nullptr, 0, LIN ? nullptr : SQLLM_PROBE_PTR(sg));
   } else if (sp >= gm.csr_blocks && sp < gm.csr_blocks + gm.topx_blocks) {

@@ -65,6 +65,7 @@ struct KernelGeom {
   int nnz, topX;
   int sparse_last;      // 1: CSR / top-X workgroups come after the dense ones in the grid
   int fold_csr;         // 1: the CSR term is walked by the dense workgroups themselves (fused small launch: csr_tile_fold_staged; csr_blocks = 0)
+  int csr_wide;         // 1: the CSR workgroups take 2 * kCsrChunk non-zeros each (csr_blocks counts those)
   int dense_prio;       // issue priority inside a batch-1 launch with sparse roles (sqllm_capi.hip: set_role_priority): 1 = the dense workgroups' waves at s_setprio 1, 2 = the CSR / top-X workgroups' waves, 0 = all equal
 };
 

@@ -67,7 +67,9 @@ __device__ __forceinline__ void xt_walk(const int* st, const float* __restrict__
 //   (Wide batches read a transposed copy of vec instead -- lane = batch row, xt_walk above or the scalar
 //   walk inside.)
 // ------------------------------------------------------------------------------------------------
-template <int T, int BT, typename XT, typename AT, bool XTMODE = false, bool XCOH = false, typename GATE = NoGate>
+// CH: non-zeros per workgroup -- kCsrChunk, or (batch-1 operator launches that exceed the resident slots: sqllm_capi.hip, widen_csr_chunks) twice
+// that: half as many, twice as deep workgroups in front of a multi-round grid.
+template <int T, int BT, typename XT, typename AT, bool XTMODE = false, bool XCOH = false, typename GATE = NoGate, int CH = kCsrChunk>
 __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
                                          const int* __restrict__ rows, const int* __restrict__ cols,
                                          const float* __restrict__ vals, int nnz, int K, int N, int b0,
@@ -80,8 +82,10 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
   // is recomputed per item -- hoisted out of that loop it would be live across every other role of the kernel)
   if constexpr (XCOH) asm volatile("" : "+v"(tid_));
   const int tid = tid_;
-  const int e0 = chunk * kCsrChunk;
-  int e1 = e0 + kCsrChunk;
+  static_assert(!XTMODE || CH == kCsrChunk, "the transposed-vec walks stage their planes kCsrChunk apart");
+  static_assert(CH == kCsrChunk || sizeof(AT) == 4, "the fused linear counts a row's chunks in units of kCsrChunk");
+  const int e0 = chunk * CH;
+  int e1 = e0 + CH;
   if (e1 > nnz) e1 = nnz;
   if (e0 >= e1) return;
   // measurement library only (sqllm_probe.h: the bits are the constant 0 in the product and all of this folds away):
@@ -94,7 +98,7 @@ __device__ __forceinline__ void csr_role(const XT* x, AT* __restrict__ y,
 #define SQLLM_CSR_STAMP(I) SQLLM_PROBE(tl, I, tid == 0);
 
   // ---- round 1 ----
-  constexpr int EPT = kCsrChunk / T;  // non-zeros per thread
+  constexpr int EPT = CH / T;  // non-zeros per thread
   static_assert(EPT >= 2, "a lane holds a run of consecutive non-zeros");
   int col[EPT];
   float val[EPT];

@@ -125,8 +125,12 @@ def test_plan_geometry():
         pf = _lib.plan_query(4, 5120, 13824, nnz=330_000, topX=10, batch=b)
         assert pf["csr_blocks"] == 0 and pf["topx_blocks"] == 20 and pf["grid_x"] == 24 + pf["dense_blocks"] <= 512, (b, pf)
     assert _lib.plan_query(4, 13824, 5120, nnz=330_000, topX=10, batch=8)["topx_blocks"] == 16
-    for b in (1, 17):
-        assert _lib.plan_query(4, 5120, 13824, nnz=330_000, topX=10, batch=b)["csr_blocks"] == -(-330_000 // 1024)
+    assert _lib.plan_query(4, 5120, 13824, nnz=330_000, topX=10, batch=17)["csr_blocks"] == -(-330_000 // 1024)
+    # batch 1, a launch of more workgroups than the chip holds with >= 1.25 x CUs of them sparse: CSR chunks of 2048 non-zeros (round 6) ...
+    assert _lib.plan_query(4, 5120, 13824, nnz=330_000, topX=10, batch=1)["csr_blocks"] == -(-330_000 // 2048)
+    # ... a launch that is resident at once keeps 1024 (7B o_proj: 512 dense + 74 + 16), and so does one with few sparse workgroups
+    assert _lib.plan_query(4, 4096, 4096, nnz=75_000, topX=10)["csr_blocks"] == 74
+    assert _lib.plan_query(4, 11008, 4096, nnz=203_000, topX=10)["csr_blocks"] == 199  # (7B down_proj: 1202 workgroups, 242 of them sparse < 320)
     assert _lib.plan_query(4, 5120, 5120, nnz=128_000, topX=10, batch=2)["csr_blocks"] == 125
     total = pm["col_tiles"] * (5120 // 8)
     assert pm["dense_blocks"] * pm["groups_per_wave"] >= total > (pm["dense_blocks"] - 1) * pm["groups_per_wave"]

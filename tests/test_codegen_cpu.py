@@ -121,7 +121,7 @@ def test_three_bit_batch1_decode_uses_pair_lookups(asm):
         b32 = sum(1 for l in body if re.match(r"\s+ds_read_b32", l))
         pk = sum(1 for l in body if re.match(r"\s+v_pk_fma_f32", l))
         assert b64 >= 128 and pk >= 128, (name, b64, pk)  # two copies of the step (first chunk + loop) x 64
-        assert b32 <= 32, (name, b32)                       # epilogue / sparse roles (row searches) only
+        assert b32 <= 64, (name, b32)                       # epilogue / sparse roles (row searches; the operator kernel carries the CSR role at two chunk sizes) only
 
 
 # ---- round 2: the batched kernel families ----

@@ -286,6 +286,13 @@ chunks)
   (bash tools/ab_libs.sh "c1024 c2048 t512 t128" "7b-w4-s45 7b-w3-s45 13b-w4-s45" 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/r06_sparse_granularity_ab.txt
   cat gpurun_out/r06_sparse_granularity_ab.txt | cut -c1-60
   ;;
+wide_chunks)
+  # libwide.so = this tree (CSR chunks of 2048 non-zeros in batch-1 launches that exceed the resident slots with >= 1.25 x CUs sparse workgroups) against libprev.so (1024 everywhere);
+  # parity of the wide role first (7B / 13B / 65B shapes at batch 1 against the C oracle)
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libwide.so timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_decoder_layer.py tests/test_gpu_batched.py -m gpu -q -p no:cacheprovider -k "llama7b or llama65b or decoder_layer or sparse_edge" 2>&1 | tail -2)
+  (bash tools/ab_libs.sh "prev wide" "7b-w4-s45 7b-w3-s45 13b-w4-s45 65b-w3-s45" 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/r06_wide_chunks_ab.txt
+  cat gpurun_out/r06_wide_chunks_ab.txt
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
