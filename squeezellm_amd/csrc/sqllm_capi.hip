@@ -177,13 +177,14 @@ void set_role_priority(sqllm::Segment* segs, int n, int bits, int batch, int tot
   for (int i = 0; i < n; ++i) segs[i].gm.dense_prio = prio;
 }
 
-// CSR chunks of 2 * kCsrChunk non-zeros in BATCH-1 operator launches that exceed the resident slots AND carry many sparse workgroups (>= 1.25 x
+// CSR chunks of 2 * kCsrChunk non-zeros in operator launches of the fused kernel that exceed the resident slots AND carry many sparse workgroups (>= 1.25 x
 // CUs at kCsrChunk each): half as many workgroups in front of the grid, each with twice the non-zeros in the same chain of round trips.  A build with
 // 2048 everywhere (profiles/r06_sparse_granularity_ab.txt) showed both sides: gate/up -2.7...-6.4 % (7B 430 / 13B 702 sparse workgroups), 13B
 // down_proj -5.7 % (365), 13B q/k/v -3 % (408), against o_proj +13...+29 % (its fewer, longer sparse workgroups become the launch's tail), 7B q/k/v
 // +1-1.5 % (270) and the 7B 3-bit down_proj +13 % (fits: dense priority).  Returns true if it widened; `*total` is recomputed then.
+// The batch tiles of up to 5 rows take part (three workgroups per CU there): 13B s45 layer at 2 / 4 / 5 rows -1.7 / -1.1 / -1.1 % (r06_wide_chunks_tiles.txt).
 bool widen_csr_chunks(sqllm::Segment* segs, int n, int batch, int* total) {
-  if (batch > 1 || *total <= 4 * cu_count() || (segs[0].gm.sparse_last & 1)) return false;
+  if (batch > 5 || *total <= (batch > 1 ? 3 : 4) * cu_count() || (segs[0].gm.sparse_last & 1)) return false;
   int sparse = 0;
   for (int i = 0; i < n; ++i) sparse += segs[i].gm.csr_blocks + segs[i].gm.topx_blocks;
   if (4 * sparse < 5 * cu_count()) return false;

@@ -517,7 +517,7 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
                                          d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds, sg, LIN ? &sg : nullptr);
   } else if (sp >= 0 && sp < gm.csr_blocks) {
     if (gm.dense_prio == 2) __builtin_amdgcn_s_setprio(1);  // (the sparse workgroups first out of the way: set_role_priority)
-    if constexpr (BT == 1 && !LIN) {
+    if constexpr (BT <= 5 && !LIN) {  // (the 6-row tile would spill with the wide role in it)
       if (gm.csr_wide) {  // (half as many, twice as deep: widen_csr_chunks)
         csr_role<T, BT, XT, AT, false, false, NoGate, 2 * kCsrChunk>(x, reinterpret_cast<AT*>(sg.y), sg.rows, sg.cols, sg.vals, gm.nnz, gm.K, gm.N, b0, nb, sp, lds,
                                                                      nullptr, gm.sparse_last >> 1, nullptr, 0, SQLLM_PROBE_PTR(sg));

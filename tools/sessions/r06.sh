@@ -293,6 +293,20 @@ wide_chunks)
   (bash tools/ab_libs.sh "prev wide" "7b-w4-s45 7b-w3-s45 13b-w4-s45 65b-w3-s45" 3 2>&1 | grep -v amdgpu.ids) > gpurun_out/r06_wide_chunks_ab.txt
   cat gpurun_out/r06_wide_chunks_ab.txt
   ;;
+wide_tiles)
+  # wide CSR chunks on the batch tiles too (libv20.so: up to 5 rows, launches of more than 3 x CUs workgroups) against this tree (libhead.so: batch 1 only); 13B w4 s45 layer
+  E=tools/experiments/small_batch_r05.py
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libv20.so timeout 600 python -m pytest tests/test_gpu_decoder_layer.py tests/test_gpu_batched.py -m gpu -q -p no:cacheprovider -k "decoder_layer or test_batch_tiles or llama13b" 2>&1 | tail -1)
+  for rep in 1 2 3; do for v in head v20; do
+    (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$v.so timeout 300 python $E --rows 2,3,4,5 2>&1 | grep '^{' | sed "s/^{/{\"variant\": \"$v\", /") >> gpurun_out/r06_wide_chunks_tiles.txt
+  done; done
+  python - <<'PY'
+import json
+for l in open("gpurun_out/r06_wide_chunks_tiles.txt"):
+    d = json.loads(l)
+    print(d["variant"], d["rows"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
+PY
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
