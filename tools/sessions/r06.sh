@@ -307,6 +307,19 @@ for l in open("gpurun_out/r06_wide_chunks_tiles.txt"):
     print(d["variant"], d["rows"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
 PY
   ;;
+envknobs)
+  # HIP runtime knobs that could move the launch boundary inside a replayed graph (~1.5 us x 128 launches per 7B token): same box, alternating, two repetitions
+  # each; 7b-w4-s0 default line (graph replay), value = tokens/s, ms = wall per token, sum = sum of the four per-shape kernel means x 32 (events)
+  for rep in 1 2; do
+  for e in "BASE=1" "HIP_FORCE_DEV_KERNARG=1" "HIP_FORCE_DEV_KERNARG=0" "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0" "AMD_OPT_FLUSH=0" "ROC_SYSTEM_SCOPE_SIGNAL=0" "GPU_MAX_HW_QUEUES=1" "DEBUG_HIP_GRAPH_BATCH_SIZE=256" "ROC_USE_FGS_KERNARG=0" "DEBUG_HIP_KERNARG_COPY_OPT=0"; do
+    (env $e timeout 200 python bench.py --config 7b-w4-s0 --no-cpu-baseline --no-sub-records 2>&1 | grep "^{" | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('$e', d['value'], d['ms_per_step'], round(32 * sum(v['us_mean'] for v in d['per_layer_us'].values()) / 1e3, 4), {k: v['us_mean'] for k, v in d['per_layer_us'].items()})
+") >> gpurun_out/r06_env_knobs.txt
+  done; done
+  cat gpurun_out/r06_env_knobs.txt
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
