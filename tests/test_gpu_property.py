@@ -3,6 +3,8 @@ every draw is checked against the fp64 oracle, through the operator names (by on
 tests/helpers.py:call_op, drawn too) and through the fused fp16 linear.  Shapes cover everything the C ABI accepts (K % 32 == 0, N % 4 == 0): ragged last
 column tiles, K slices with ragged ends, single-step and many-step slices, empty CSR, batch tiles
 with a ragged last tile."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings
@@ -31,7 +33,11 @@ def _npl(lay):
     return {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in lay.items()}
 
 
-@settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+# SQLLM_PROPERTY_EXAMPLES=<n> (bug hunts: tools/sessions/r06.sh fuzz) draws n fresh, non-derandomised examples instead of the suite's fixed 150
+_N_EXAMPLES = int(os.environ.get("SQLLM_PROPERTY_EXAMPLES", "0"))
+
+
+@settings(max_examples=_N_EXAMPLES or 150, deadline=None, derandomize=not _N_EXAMPLES, database=None, suppress_health_check=list(HealthCheck))
 @given(case=CASE)
 def test_random_shapes_operator_and_fused_linear(gpu, case):
     import torch

@@ -320,6 +320,13 @@ print('$e', d['value'], d['ms_per_step'], round(32 * sum(v['us_mean'] for v in d
   done; done
   cat gpurun_out/r06_env_knobs.txt
   ;;
+fuzz)
+  # bug hunt: the randomised GPU parity test with fresh (non-derandomised) draws, three processes of FUZZ_N (default 1500) examples each
+  for i in 1 2 3; do
+    (SQLLM_PROPERTY_EXAMPLES=${FUZZ_N:-1500} timeout 1500 python -m pytest tests/test_gpu_property.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -25) > gpurun_out/r06_fuzz_$i.log
+    tail -3 gpurun_out/r06_fuzz_$i.log
+  done
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
