@@ -327,6 +327,13 @@ fuzz)
     tail -3 gpurun_out/r06_fuzz_$i.log
   done
   ;;
+fuzz_large)
+  # bug hunt at large shapes (multi-round launches, wide CSR chunks, role priorities, groups of 1-4 ops): the suite's 24 fixed draws, then FUZZ_N fresh ones
+  (timeout 1200 python -m pytest tests/test_gpu_fuzz_large.py -m gpu -q -p no:cacheprovider 2>&1 | tail -15) > gpurun_out/r06_fuzz_large_fixed.log
+  tail -3 gpurun_out/r06_fuzz_large_fixed.log
+  (SQLLM_FUZZ_LARGE=${FUZZ_N:-200} timeout 2400 python -m pytest tests/test_gpu_fuzz_large.py -m gpu -q -p no:cacheprovider 2>&1 | tail -40) > gpurun_out/r06_fuzz_large_fresh.log
+  tail -5 gpurun_out/r06_fuzz_large_fresh.log
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
