@@ -182,9 +182,10 @@ void set_role_priority(sqllm::Segment* segs, int n, int bits, int batch, int tot
 // 2048 everywhere (profiles/r06_sparse_granularity_ab.txt) showed both sides: gate/up -2.7...-6.4 % (7B 430 / 13B 702 sparse workgroups), 13B
 // down_proj -5.7 % (365), 13B q/k/v -3 % (408), against o_proj +13...+29 % (its fewer, longer sparse workgroups become the launch's tail), 7B q/k/v
 // +1-1.5 % (270) and the 7B 3-bit down_proj +13 % (fits: dense priority).  Returns true if it widened; `*total` is recomputed then.
-// The batch tiles of up to 5 rows take part (three workgroups per CU there): 13B s45 layer at 2 / 4 / 5 rows -1.7 / -1.1 / -1.1 % (r06_wide_chunks_tiles.txt).
-bool widen_csr_chunks(sqllm::Segment* segs, int n, int batch, int* total) {
-  if (batch > 5 || *total <= (batch > 1 ? 3 : 4) * cu_count() || (segs[0].gm.sparse_last & 1)) return false;
+// The batch tiles of up to 5 rows take part (three workgroups per CU there, four in the 4-bit 2-row tile): 13B s45 layer at 2 / 4 / 5 rows -1.7 / -1.1 / -1.1 % (r06_wide_chunks_tiles.txt).
+bool widen_csr_chunks(sqllm::Segment* segs, int n, int bits, int batch, int* total) {
+  const int resident = (batch <= 1 || (batch == 2 && bits == 4)) ? 4 : 3;  // (workgroups per CU of the tile that serves `batch` rows: sqllm_fused.h, fused_min_waves)
+  if (batch > 5 || *total <= resident * cu_count() || (segs[0].gm.sparse_last & 1)) return false;
   int sparse = 0;
   for (int i = 0; i < n; ++i) sparse += segs[i].gm.csr_blocks + segs[i].gm.topx_blocks;
   if (4 * sparse < 5 * cu_count()) return false;
@@ -433,7 +434,9 @@ int cols_min_batch_of() {
 bool cols_pays(const sqllm_op* op, int n_ops) {
   if (knobs().cols_min_batch.load(std::memory_order_relaxed) > 0 || knobs().cols_max_batch.load(std::memory_order_relaxed) > 0) return true;
   const double mb = (double)op->K * op->N * op->bits / 8e6;  // (of a group: the sum of its ops)
-  if (op->bits == 4) return (n_ops >= 3 && op->batch <= 4) || (n_ops == 1 && mb >= 20.0);
+  // (round 6: the 4-bit 2-row tile went to four workgroups per CU -- a three-op group WITH sparse terms of >= 32 MB is then faster on the tiles at exactly
+  // 2 rows: 13B q/k/v 17.1 -> 15.4 us, 65B 35 -> 32; 7B's 25 MB and every dense-only group stay here: profiles/r06_tile2_half.txt)
+  if (op->bits == 4) return (n_ops >= 3 && op->batch <= 4 && !(op->batch == 2 && op->nnz > 0 && mb >= 32.0)) || (n_ops == 1 && mb >= 20.0);
   if (op->batch <= 4 && mb >= 16.0) return true;
   return op->N >= 8192;
 }
@@ -568,7 +571,7 @@ int sqllm_plan_query(const sqllm_op* op, sqllm_plan* plan) {
     sqllm::Segment one;  // (as launched alone: a batch-1 launch that exceeds the resident slots may take wide CSR chunks)
     one.gm = gm;
     int total = (gm.dense_block0 + gm.dense_blocks + 7) / 8 * 8;
-    (void)widen_csr_chunks(&one, 1, op->batch, &total);
+    (void)widen_csr_chunks(&one, 1, op->bits, op->batch, &total);
     gm = one.gm;
   }
   const bool small_split = mfma && !wide && takes_small_split(op);
@@ -967,7 +970,7 @@ static int launch_group_with_events(const sqllm_op* ops, int n, sqllm_stream_t s
   for (int i = n; i <= sqllm::kMaxSegments; ++i) a.ga.block0[i] = block;
   for (int i = n; i < sqllm::kMaxSegments; ++i) memset(&a.ga.seg[i], 0, sizeof(sqllm::Segment));
   if (!lin) {
-    const bool widened = widen_csr_chunks(a.ga.seg, n, ops[0].batch, &block);
+    const bool widened = widen_csr_chunks(a.ga.seg, n, ops[0].bits, ops[0].batch, &block);
     if (widened) {
       int at = 0;
       for (int i = 0; i < n; ++i) {

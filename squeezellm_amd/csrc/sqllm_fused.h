@@ -193,8 +193,9 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   static_assert(!PAIR || (WAVES == 8 && BT == 1), "pair tables: wave w stages second index w");
   constexpr int ESTRIDE = (BITS == 4) ? 256 : 128;                 // bytes between consecutive entries
   constexpr int SUBB = (BITS == 4) ? (L * ESTRIDE) / 2 : L * ESTRIDE;  // LDS bytes per column sub-table
-  // steps per chunk (4-bit: even, steps pair up for x; 3-bit: 12 VGPRs of weights per step)
-  constexpr int NBUF = (BITS == 4) ? (BT <= 2 ? 4 : 2) : ((BT == 1 && !HALF) ? 2 : 1);
+  // steps per chunk (4-bit: even, steps pair up for x -- four at batch 1, two in the batch tiles: the 2-row tile fits 64 VGPRs with two;
+  // 3-bit: 12 VGPRs of weights per step)
+  constexpr int NBUF = (BITS == 4) ? (BT == 1 ? 4 : 2) : ((BT == 1 && !HALF) ? 2 : 1);
   constexpr int NXR = (BITS == 4) ? NBUF / 2 : 2 * NBUF;  // x registers per chunk and batch row
   constexpr int STEP = WAVES * 4;                // units a workgroup step covers
   const int tid = threadIdx.x;
@@ -459,16 +460,20 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
 // halving the live lookups won up to 18 %): the decode stages work on one column pair at a time
 // (16 live lookups instead of 32), which lets the batch-1 kernels fit 64 VGPRs, i.e. FOUR 8-wave
 // workgroups per CU; the wider batch tiles take what they need up to 128 (two per CU).
-// waves per SIMD the register allocation must leave room for (= 8-wave workgroups per CU x 2): batch 1 four workgroups (64
-// VGPRs), the 2- / 3-row and the 4-bit 4- / 5- / 6-row tiles three (80), everything wider two (128)
+// waves per SIMD the register allocation must leave room for (= 8-wave workgroups per CU x 2): batch 1 and the 4-bit 2-row tile four
+// workgroups (64 VGPRs: half stages), the 3-bit 2-row, the 3-row and the 4-bit 4- / 5- / 6-row tiles three (80), everything wider two (128)
+constexpr bool fused_half_stages(int bits, int bt) { return SQLLM_HALF_STAGES && (bt == 1 || (bt == 2 && bits == 4)); }
 constexpr int fused_min_waves(int bits, int bt, int abl) {
-  return (abl & 64) ? 8 : ((bt == 1 && SQLLM_HALF_STAGES) ? 8 : ((bt == 2 || bt == 3 || (bt >= 4 && bt <= 6 && bits == 4)) ? 6 : 4));
+  return (abl & 64) ? 8 : (fused_half_stages(bits, bt) ? 8 : ((bt == 2 || bt == 3 || (bt >= 4 && bt <= 6 && bits == 4)) ? 6 : 4));
 }
 
 template <int BITS, int BT, int WAVES, int ABL, bool LIN>
 __global__ void __launch_bounds__(WAVES * 64, fused_min_waves(BITS, BT, ABL))
 sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
-  constexpr bool HALF = SQLLM_HALF_STAGES && BT == 1;  // wider batch tiles: the per-row x broadcasts would be live twice
+  // Half stages (one column pair at a time) for batch 1 and -- round 6 -- the 4-bit 2-row tile: 63 VGPRs with two steps per chunk, the fourth
+  // workgroup per CU (13B s45 at 2 rows: o_proj 8.3 -> 7.6 us, gate/up dense-only 24.0 -> 23.2; profiles/r06_tile2_half.txt).  The 3- / 4-row
+  // tiles spill 52 / 126 registers at 64 and the 3-bit 2-row tile 5: they keep whole stages at three workgroups per CU.
+  constexpr bool HALF = fused_half_stages(BITS, BT);
   constexpr int T = WAVES * 64;
   constexpr int kLds = lds_floats(Fmt<BITS>::kLut, WAVES, BT, BITS == 3 && BT == 1 && SQLLM_HALF_STAGES && SQLLM_PAIR3);
   __shared__ __attribute__((aligned(16))) float lds[kLds];

@@ -82,6 +82,9 @@ def test_no_spills_and_occupancy_targets(asm):
         m = re.search(r"matvecILi([34])ELi(\d)ELi8ELi0ELb0", name)
         if m and (m.group(2) in "23" or (m.group(1) == "4" and m.group(2) in "456")):
             assert int(vgpr) <= 80, (name, vgpr)
+        # four per CU for the 4-bit 2-row tile, operator and fused linear (round 6: half stages, two steps per chunk)
+        if re.search(r"matvecILi4ELi2E", name):
+            assert int(vgpr) <= 64, (name, vgpr)
 
 
 def test_prologue_reads_the_argument_block_in_one_round(asm):

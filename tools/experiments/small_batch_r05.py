@@ -31,10 +31,11 @@ def main():
     ap.add_argument("--sets", default="default")
     ap.add_argument("--dense-only", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--config", default="13b-w4-s45", help="a bench.py config for the shapes (7b-w4-s45, 65b-w3-s45 ...); --bits overrides its width")
     ap.add_argument("--no-ws", action="store_true", help="the workspace-less entry points (no transposed vec for the folded CSR walk)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    cfg = dict(bench.CONFIGS["13b-w4-s45"], bits=a.bits)
+    cfg = dict(bench.CONFIGS[a.config], bits=a.bits)
     if a.dense_only:
         cfg.update(sparse=0.0, topX=0)
     layers = bench.build_layers(cfg, dev, 0, 4)
@@ -50,7 +51,7 @@ def main():
     for B in [int(r) for r in a.rows.split(",")]:
         xs, ys = bench.decoder_inputs(layers, dev, gen, batch=0 if B == 1 else B)
         for tag, opts in sets:
-            row = dict(lib=os.path.basename(os.environ.get("SQLLM_LIB", "HEAD")), config="13b-w%d-%s" % (a.bits, "s0" if a.dense_only else "s45"), rows=B, set=tag)
+            row = dict(lib=os.path.basename(os.environ.get("SQLLM_LIB", "HEAD")), config="%s-w%d-%s" % (a.config.split("-")[0], a.bits, "s0" if a.dense_only else "s45"), rows=B, set=tag)
             try:
                 for k, v in opts.items():
                     _lib.set_option(k, v)

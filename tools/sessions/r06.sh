@@ -334,6 +334,21 @@ fuzz_large)
   (SQLLM_FUZZ_LARGE=${FUZZ_N:-200} timeout 2400 python -m pytest tests/test_gpu_fuzz_large.py -m gpu -q -p no:cacheprovider 2>&1 | tail -40) > gpurun_out/r06_fuzz_large_fresh.log
   tail -5 gpurun_out/r06_fuzz_large_fresh.log
   ;;
+tile2_half)
+  # the 4-bit 2-row batch tile on half stages at 64 VGPRs / NBUF 2 (four workgroups per CU; libv21.so, tools/build_variant.sh) against this tree (libhead.so): parity, then 13B s45 layer at 2 rows
+  E=tools/experiments/small_batch_r05.py
+  (SQLLM_LIB=$PWD/squeezellm_amd/ab/libv21.so timeout 600 python -m pytest tests/test_gpu_decoder_layer.py tests/test_gpu_batched.py -m gpu -q -p no:cacheprovider -k "decoder_layer or test_batch_tiles or llama13b" 2>&1 | tail -1)
+  for rep in 1 2 3; do for v in head v21; do
+    (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$v.so timeout 300 python $E --rows 2 2>&1 | grep '^{' | sed "s/^{/{\"variant\": \"$v\", /") >> gpurun_out/r06_tile2_half.txt
+    (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$v.so timeout 300 python $E --rows 2 --dense-only 2>&1 | grep '^{' | sed "s/^{/{\"variant\": \"$v\", \"dense_only\": 1, /") >> gpurun_out/r06_tile2_half.txt
+  done; done
+  python - <<'PY'
+import json
+for l in open("gpurun_out/r06_tile2_half.txt"):
+    d = json.loads(l)
+    print(d["variant"], d.get("dense_only", 0), d["rows"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
+PY
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
