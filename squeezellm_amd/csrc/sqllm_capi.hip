@@ -128,6 +128,12 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch, int
       const bool dense_only = !(op->rows && op->nnz > 0) && !(op->full_rows && op->topX > 0);
       const double two_per_cu_mb = (op->bits == 3 && dense_only) ? 18.0 : 16.0;
       target = (mb <= 12.0 ? (alone ? 2 : 1) : (!alone && mb <= two_per_cu_mb) ? 2 : (alone ? 4 : 3)) * cu_count();
+      // ... and "4 when alone" presumes the four resident workgroups per CU of the batch-1 kernel (and of the 4-bit 2-row tile).  On the batch tiles
+      // that hold THREE (4-bit: 3-6 rows; 3-bit: 2-3 rows) the 13B o_proj's 800 workgroups were one round of 768 plus 32 stragglers: 2.5 per CU
+      // (560 workgroups, the sparse ones fit beside them) -- 13B s45 o_proj at 3 / 4 / 5 / 6 rows 9.4 / 10.0 / 11.4 / 12.65 -> 7.6 / 9.15 / 11.15 / 12.5 us
+      // (profiles/r06_oproj_one_round.txt); the 7- / 8-row tiles (two per CU) measured no difference at any count.
+      const int bt = sqllm::batch_tile_op(gm->batch);
+      if (alone && mb > 12.0 && (op->bits == 4 ? (bt >= 3 && bt <= 6) : (bt == 2 || bt == 3))) target = 5 * cu_count() / 2;
       if (waves > sqllm::kWaves) target = target * sqllm::kWaves / waves;  // (16-wave workgroups: half as many, twice the rows each)
     }
     int slices = (target + gm->col_tiles / 2) / gm->col_tiles;

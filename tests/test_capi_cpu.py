@@ -79,7 +79,9 @@ def test_plan_geometry():
     # 3: they fit three workgroups per CU and measure faster), large ops take the column-lane kernel
     assert _lib.get_option("cols_min_batch") == 0 and _lib.get_option("cols_max_batch") == 0
     pt = _lib.plan_query(4, 5120, 5120, batch=4)
-    assert pt["dense_blocks"] == pt["col_tiles"] * pt["k_slices"] and pt["dense_blocks"] >= 800  # batch tiles: column tiles x K slices
+    # batch tiles: column tiles x K slices; an op of > 12 MB alone on a tile that holds three workgroups per CU is planned as ONE resident round (2.5 per CU, round 6)
+    assert pt["dense_blocks"] == pt["col_tiles"] * pt["k_slices"] and pt["dense_blocks"] == 560
+    assert _lib.plan_query(4, 5120, 5120, batch=2)["dense_blocks"] == 800 == _lib.plan_query(4, 5120, 5120, batch=0)["dense_blocks"]  # four per CU there
     pc = _lib.plan_query(3, 5120, 13824, batch=4)
     total = pc["col_tiles"] * (5120 // 32)
     assert pc["grid_y"] == 1 and pc["groups_per_wave"] % 8 == 0 and 700 <= pc["dense_blocks"] <= 768

@@ -349,6 +349,14 @@ for l in open("gpurun_out/r06_tile2_half.txt"):
     print(d["variant"], d.get("dense_only", 0), d["rows"], d["layer_us"], d.get("qkv"), d.get("o"), d.get("gate_up"), d.get("down"))
 PY
   ;;
+oproj_one_round)
+  # an op of > 12 MB alone in its launch on a tile that holds three workgroups per CU: planned as one resident round (libtree2.so) against 800 workgroups (libtree.so)
+  E=tools/experiments/small_batch_r05.py
+  for rep in 1 2; do timeout 600 python $E --config 13b-w4-s45 --rows 3,4,5,6,7,8 --sets "default;target_wgs=768;target_wgs=640;target_wgs=512;target_wgs=400" 2>&1 | grep "^{"; done > gpurun_out/r06_oproj_target_sweep.txt
+  for rep in 1 2 3; do for v in tree tree2; do
+    (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$v.so timeout 300 python $E --config 13b-w4-s45 --rows 3,4,5,6 2>&1 | grep '^{' | sed "s/^{/{\"variant\": \"$v\", /") >> gpurun_out/r06_oproj_one_round.txt
+  done; done
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
