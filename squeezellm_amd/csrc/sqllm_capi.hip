@@ -259,6 +259,13 @@ void make_plan_mfma(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch
       const long long n_even = (long long)gm->col_tiles * ((gm->units_total + even - 1) / even);
       if (n_even <= ranges && 10 * n_even >= 9 * ranges) { upw = even; aligned = true; }
     }
+    // Measured exception (profiles/r06_launch_geometry_cols.txt): a 4-bit group of three ops WITH sparse terms whose aligned cut is three
+    // UNEVEN ranges per tile (K = 5120: 216 / 216 / 208 units) is 5-7 % faster on two even ones -- 13B q/k/v at 3 / 4 rows 19.5 / 22.0 ->
+    // 18.6 / 20.5 us (four per tile: 18.8 / 20.8; the 408 sparse workgroups hold half the slots first).  Not so dense-only, at 3 bits, or where
+    // the cut is even already (7B, 65B: fewer ranges cost 5-17 % there).
+    if (aligned && ops_in_launch >= 3 && op->bits == 4 && gm->nnz > 0 && (gm->units_total + upw - 1) / upw == 3 &&
+        gm->units_total % upw != 0 && gm->units_total % (2 * sqllm::kWaves) == 0)
+      upw = gm->units_total / 2;
   }
   upw = (upw + step - 1) / step * step;
   if (upw > 0x3fffffff) upw = 0x3fffffff / step * step;
@@ -412,6 +419,13 @@ void make_plan_cols(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch
       const long long n_even = (long long)gm->col_tiles * ((gm->units_total + even - 1) / even);
       if (n_even <= ranges && 10 * n_even >= 9 * ranges) { upw = even; aligned = true; }
     }
+    // Measured exception (profiles/r06_launch_geometry_cols.txt): a 4-bit group of three ops WITH sparse terms whose aligned cut is three
+    // UNEVEN ranges per tile (K = 5120: 216 / 216 / 208 units) is 5-7 % faster on two even ones -- 13B q/k/v at 3 / 4 rows 19.5 / 22.0 ->
+    // 18.6 / 20.5 us (four per tile: 18.8 / 20.8; the 408 sparse workgroups hold half the slots first).  Not so dense-only, at 3 bits, or where
+    // the cut is even already (7B, 65B: fewer ranges cost 5-17 % there).
+    if (aligned && ops_in_launch >= 3 && op->bits == 4 && gm->nnz > 0 && (gm->units_total + upw - 1) / upw == 3 &&
+        gm->units_total % upw != 0 && gm->units_total % (2 * sqllm::kWaves) == 0)
+      upw = gm->units_total / 2;
   }
   upw = (upw + sqllm::kWaves - 1) / sqllm::kWaves * sqllm::kWaves;
   if (upw > 0x3fffffff) upw = 0x3fffffff / sqllm::kWaves * sqllm::kWaves;
