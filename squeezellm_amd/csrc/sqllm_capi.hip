@@ -128,18 +128,36 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch, int
       const bool dense_only = !(op->rows && op->nnz > 0) && !(op->full_rows && op->topX > 0);
       const double two_per_cu_mb = (op->bits == 3 && dense_only) ? 18.0 : 16.0;
       target = (mb <= 12.0 ? (alone ? 2 : 1) : (!alone && mb <= two_per_cu_mb) ? 2 : (alone ? 4 : 3)) * cu_count();
-      // ... and "4 when alone" presumes the four resident workgroups per CU of the batch-1 kernel (and of the 4-bit 2-row tile).  On the batch tiles
-      // that hold THREE (4-bit: 3-6 rows; 3-bit: 2-3 rows) the 13B o_proj's 800 workgroups were one round of 768 plus 32 stragglers: 2.5 per CU
-      // (560 workgroups, the sparse ones fit beside them) -- 13B s45 o_proj at 3 / 4 / 5 / 6 rows 9.4 / 10.0 / 11.4 / 12.65 -> 7.6 / 9.15 / 11.15 / 12.5 us
-      // (profiles/r06_oproj_one_round.txt); the 7- / 8-row tiles (two per CU) measured no difference at any count.
-      const int bt = sqllm::batch_tile_op(gm->batch);
-      if (alone && mb > 12.0 && (op->bits == 4 ? (bt >= 3 && bt <= 6) : (bt == 2 || bt == 3))) target = 5 * cu_count() / 2;
       if (waves > sqllm::kWaves) target = target * sqllm::kWaves / waves;  // (16-wave workgroups: half as many, twice the rows each)
     }
     int slices = (target + gm->col_tiles / 2) / gm->col_tiles;
     if (slices < 1) slices = 1;
     if (slices > max_slices) slices = max_slices;
     upw = (gm->units_total + slices - 1) / slices;
+    // ONE resident round for an op alone in its launch on a batch tile that holds two or three workgroups per CU (round 6).  The targets above
+    // presume the batch-1 kernel's four: on a narrower residency the same plan is a full round plus a few stragglers, which start when the first
+    // workgroups END -- 13B o_proj (4-bit, 3-6 rows, three per CU): 800 (+136 sparse) against 768 slots, 9.4 / 10.0 -> 7.6 / 9.15 us at 3 / 4 rows with
+    // 560; 7B o_proj (4-bit, 7-8 rows, two per CU): 512 + 90 against 512, 11.6 / 13.3 -> 10.75 / 12.1 with 384; 13B o_proj at 3 bits (4-8 rows): 400 +
+    // 136 against 512, -6...-11 % with 240 (profiles/r06_oproj_one_round.txt).  So: if dense + sparse workgroups exceed the slots by up to 35 %,
+    // take the K slices that fit beside the sparse workgroups.  Not at four per CU (batch 1: 7B down_proj 960 + 242 against 1024 is 3 % FASTER than
+    // 768 + 242), not for launches that are several rounds anyway, not for groups (flat: r06_launch_geometry_cols.txt, last block).
+    const int bt = sqllm::batch_tile_op(gm->batch);
+    const int per_cu = (bt == 1 || (bt == 2 && op->bits == 4)) ? 4 : (op->bits == 4 ? (bt <= 6 ? 3 : 2) : (bt <= 3 ? 3 : 2));
+    if (ops_in_launch <= 1 && per_cu <= 3 && knobs().target_wgs.load(std::memory_order_relaxed) <= 0) {
+      const int slots = per_cu * cu_count();
+      const int sparse = ((op->rows && op->nnz > 0) ? (op->nnz + sqllm::kCsrChunk - 1) / sqllm::kCsrChunk : 0) +
+                         ((op->full_rows && op->topX > 0) ? (op->K + sqllm::kTopxRows - 1) / sqllm::kTopxRows : 0);
+      auto dense_of = [&](int sl) {
+        int u = (gm->units_total + sl - 1) / sl;
+        u = (u + step - 1) / step * step;
+        return gm->col_tiles * ((gm->units_total + u - 1) / u);
+      };
+      const int total = dense_of(slices) + sparse;
+      if (total > slots && 100ll * total <= 135ll * slots) {
+        while (slices > 1 && dense_of(slices) + sparse > slots) --slices;
+        upw = (gm->units_total + slices - 1) / slices;
+      }
+    }
   }
   upw = (upw + step - 1) / step * step;
   gm->units_per_wg = upw;
