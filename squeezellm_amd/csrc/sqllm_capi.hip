@@ -160,6 +160,12 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch, int
     }
   }
   upw = (upw + step - 1) / step * step;
+  // 4-bit batch-1 waves work in chunks of four steps (128 units per workgroup, sqllm_fused.h: NBUF): a K slice of ONE chunk plus ONE step -- 160 units, the
+  // 13B gate/up and down_proj under the size classes above -- pays a second round of loads for a quarter of a chunk.  One chunk per slice instead
+  // (more slices): 13B s45 gate/up 22.2-22.8 -> 21.2-21.9 us, down_proj 12.85-13.5 -> 12.2-12.35 (profiles/r06_launch_geometry_b1.txt).
+  if (op->bits == 4 && gm->batch == 1 && waves == sqllm::kWaves && knobs().groups_per_wave.load(std::memory_order_relaxed) <= 0 &&
+      knobs().target_wgs.load(std::memory_order_relaxed) <= 0 && upw == 5 * step && (gm->units_total + 4 * step - 1) / (4 * step) <= max_slices)
+    upw = 4 * step;
   gm->units_per_wg = upw;
   gm->k_slices = (gm->units_total + upw - 1) / upw;
   gm->dense_blocks = gm->col_tiles * gm->k_slices;
