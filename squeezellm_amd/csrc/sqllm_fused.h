@@ -175,7 +175,7 @@ __device__ __forceinline__ void dense_epilogue(const f32x2 (&acc)[2][BT], float*
 // address arithmetic cost more VALU than the overlap returns), and up to 32 waves per CU at different
 // phases keep the memory pipe busy.
 // ------------------------------------------------------------------------------------------------
-template <int BITS, int BT, int WAVES, int ABL, typename XT, bool HALF = false>
+template <int BITS, int BT, int WAVES, int ABL, typename XT, bool HALF = false, bool SHORT = false>
 __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* __restrict__ y,
                                            const float* lut, int K, int N, int b0, int nb, int bid,
                                            int n_col_tiles, int units_total, int units_per_wg, float* lds,
@@ -195,7 +195,9 @@ __device__ __forceinline__ void dense_role(const XT* x, const u32x4* q, float* _
   constexpr int SUBB = (BITS == 4) ? (L * ESTRIDE) / 2 : L * ESTRIDE;  // LDS bytes per column sub-table
   // steps per chunk (4-bit: even, steps pair up for x -- four at batch 1, two in the batch tiles: the 2-row tile fits 64 VGPRs with two;
   // 3-bit: 12 VGPRs of weights per step)
-  constexpr int NBUF = (BITS == 4) ? (BT == 1 ? 4 : 2) : ((BT == 1 && !HALF) ? 2 : 1);
+  // SHORT (4-bit batch 1, chosen per launch by the host: launch_bt): every K slice of the launch is at most TWO steps per wave (o_proj: 64 units) -- a chunk
+  // of two then issues no loads it will not decode (the chunk of four re-read the slice's last unit twice): o_proj 4.83 -> 4.65 us (profiles/r06_short_chunks.txt)
+  constexpr int NBUF = (BITS == 4) ? ((BT == 1 && !SHORT) ? 4 : 2) : ((BT == 1 && !HALF) ? 2 : 1);
   constexpr int NXR = (BITS == 4) ? NBUF / 2 : 2 * NBUF;  // x registers per chunk and batch row
   constexpr int STEP = WAVES * 4;                // units a workgroup step covers
   const int tid = threadIdx.x;
@@ -467,7 +469,7 @@ constexpr int fused_min_waves(int bits, int bt, int abl) {
   return (abl & 64) ? 8 : (fused_half_stages(bits, bt) ? 8 : ((bt == 2 || bt == 3 || (bt >= 4 && bt <= 6 && bits == 4)) ? 6 : 4));
 }
 
-template <int BITS, int BT, int WAVES, int ABL, bool LIN>
+template <int BITS, int BT, int WAVES, int ABL, bool LIN, bool SHORT = false>
 __global__ void __launch_bounds__(WAVES * 64, fused_min_waves(BITS, BT, ABL))
 sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
   // Half stages (one column pair at a time) for batch 1 and -- round 6 -- the 4-bit 2-row tile: 63 VGPRs with two steps per chunk, the fourth
@@ -518,7 +520,7 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
     sp = bid < gm.dense_block0 ? bid : -1;
   }
   if (d >= 0 && d < gm.dense_blocks) {
-    dense_role<BITS, BT, WAVES, ABL, XT, HALF>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, b0, nb,
+    dense_role<BITS, BT, WAVES, ABL, XT, HALF, SHORT>(x, reinterpret_cast<const u32x4*>(sg.q), sg.y, sg.lut, gm.K, gm.N, b0, nb,
                                          d, gm.col_tiles, gm.units_total, gm.units_per_wg, lds, sg, LIN ? &sg : nullptr);
   } else if (sp >= 0 && sp < gm.csr_blocks) {
     if (gm.dense_prio == 2) __builtin_amdgcn_s_setprio(1);  // (the sparse workgroups first out of the way: set_role_priority)
@@ -538,11 +540,11 @@ sqllm_fused_matvec(const void* xv, const GroupArgs ga) {
   }
 }
 
-template <int BITS, int BT, int WAVES, int ABL = 0, bool LIN = false>
+template <int BITS, int BT, int WAVES, int ABL = 0, bool LIN = false, bool SHORT = false>
 inline hipError_t launch_inst(const LaunchArgs& a, hipStream_t stream) {
   const int batch = a.ga.seg[0].gm.batch;
   dim3 grid(a.ga.block0[a.ga.n_seg], (batch + BT - 1) / BT);
-  auto kern = sqllm_fused_matvec<BITS, BT, WAVES, ABL, LIN>;
+  auto kern = sqllm_fused_matvec<BITS, BT, WAVES, ABL, LIN, SHORT>;
   if (a.ev_start || a.ev_stop) {
     // same kernel, with the dispatch's own begin/end timestamps exposed through two events
     hipExtLaunchKernelGGL(kern, grid, dim3(WAVES * 64), a.lds_pad, stream, a.ev_start, a.ev_stop, 0, a.x, a.ga);

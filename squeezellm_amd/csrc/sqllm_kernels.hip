@@ -702,6 +702,13 @@ static hipError_t launch_bt(const LaunchArgs& a, hipStream_t stream) {
       default: break;
     }
   }
+  if constexpr (BITS == 4 && !LIN) {
+    if (batch == 1) {  // every K slice of the launch at most two steps per wave (o_proj): the kernel whose chunks are two steps (sqllm_fused.h: SHORT)
+      bool brief = true;
+      for (int i = 0; i < a.ga.n_seg; ++i) brief = brief && a.ga.seg[i].gm.units_per_wg <= 2 * kWaves * 4;
+      if (brief) return launch_inst<BITS, 1, kWaves, 0, LIN, true>(a, stream);
+    }
+  }
   switch (batch_tile(batch)) {
     case 1: return launch_inst<BITS, 1, kWaves, 0, LIN>(a, stream);
     case 2: return launch_inst<BITS, 2, kWaves, 0, LIN>(a, stream);
