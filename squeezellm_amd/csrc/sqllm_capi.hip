@@ -143,7 +143,10 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch, int
     // 768 + 242), not for launches that are several rounds anyway, not for groups (flat: r06_launch_geometry_cols.txt, last block).
     const int bt = sqllm::batch_tile_op(gm->batch);
     const int per_cu = (bt == 1 || (bt == 2 && op->bits == 4)) ? 4 : (op->bits == 4 ? (bt <= 6 ? 3 : 2) : (bt <= 3 ? 3 : 2));
-    if (ops_in_launch <= 1 && per_cu <= 3 && knobs().target_wgs.load(std::memory_order_relaxed) <= 0) {
+    // ... and, at four per CU, for a 3-BIT op alone in its batch-1 launch: a launch that fits gets the dense-wave priority (set_role_priority, rule 1) -- 65B
+    // o_proj, 1024 + 359 against 1024: 11.8 -> 11.2 us with 512 (10.85 with 384; profiles/r06_launch_geometry_b1.txt)
+    const bool w3_batch1 = per_cu == 4 && op->bits == 3 && gm->batch == 1;
+    if (ops_in_launch <= 1 && (per_cu <= 3 || w3_batch1) && knobs().target_wgs.load(std::memory_order_relaxed) <= 0) {
       const int slots = per_cu * cu_count();
       const int sparse = ((op->rows && op->nnz > 0) ? (op->nnz + sqllm::kCsrChunk - 1) / sqllm::kCsrChunk : 0) +
                          ((op->full_rows && op->topX > 0) ? (op->K + sqllm::kTopxRows - 1) / sqllm::kTopxRows : 0);
@@ -153,7 +156,7 @@ void make_plan(const sqllm_op* op, sqllm::KernelGeom* gm, int ops_in_launch, int
         return gm->col_tiles * ((gm->units_total + u - 1) / u);
       };
       const int total = dense_of(slices) + sparse;
-      if (total > slots && 100ll * total <= 135ll * slots) {
+      if (total > slots && 100ll * total <= (w3_batch1 ? 140ll : 135ll) * slots) {
         while (slices > 1 && dense_of(slices) + sparse > slots) --slices;
         upw = (gm->units_total + slices - 1) / slices;
       }
