@@ -357,6 +357,24 @@ oproj_one_round)
     (SQLLM_LIB=$PWD/squeezellm_amd/ab/lib$v.so timeout 300 python $E --config 13b-w4-s45 --rows 3,4,5,6 2>&1 | grep '^{' | sed "s/^{/{\"variant\": \"$v\", /") >> gpurun_out/r06_oproj_one_round.txt
   done; done
   ;;
+geometry)
+  # the planner against the residency of the kernel it plans for (second session): tools/experiments/launch_geometry.py sweeps of target_wgs per launch shape.  Outputs concatenated into
+  # profiles/r06_oproj_one_round.txt, r06_launch_geometry_cols.txt, r06_launch_geometry_b1.txt with the same-box A/Bs of the variant libraries (libtree..libtree7.so: the tree before each rule)
+  G=tools/experiments/launch_geometry.py
+  for b in 2 4 5; do timeout 900 python $G --shapes "gateup13:5120x13824x2,qkv13:5120x5120x3" --batch $b --sparse 0.0045 --topx 10 --targets 256,384,512,640,768,1024 2>&1 | grep "^{" >> gpurun_out/r06_launch_geometry_13b.txt; done
+  for b in 2 3 4 6; do timeout 900 python $G --shapes "down13:13824x5120x1" --batch $b --sparse 0.0045 --topx 10 --targets 320,400,480,560,640,720,800,880,960 2>&1 | grep "^{" >> gpurun_out/r06_launch_geometry_cols.txt; done
+  for b in 3 4; do timeout 900 python $G --shapes "qkv13:5120x5120x3" --batch $b --sparse 0.0045 --topx 10 --targets 320,400,480,560,640,720,800,880,960 2>&1 | grep "^{" >> gpurun_out/r06_launch_geometry_cols.txt; done
+  for b in 2 3 4; do timeout 900 python $G --bits 3 --shapes "qkv13:5120x5120x3" --batch $b --sparse 0.0045 --topx 10 --targets 480,720,960 2>&1 | grep "^{" >> gpurun_out/r06_launch_geometry_cols_w3.txt; done
+  for b in 3 4; do timeout 900 python $G --shapes "qkv7:4096x4096x3,qkv65:8192x8192x3" --batch $b --sparse 0.0045 --topx 10 --targets 384,480,576,768 2>&1 | grep "^{" >> gpurun_out/r06_launch_geometry_cols_7b65b.txt; done
+  for b in 2 3 4 5 6 8; do timeout 900 python $G --bits 3 --shapes "o13:5120x5120x1" --batch $b --sparse 0.0045 --topx 10 --targets 240,320,400,480,560,640 2>&1 | grep "^{" >> gpurun_out/r06_launch_geometry_o13_w3.txt; done
+  for b in 7 8; do timeout 900 python $G --shapes "o7:4096x4096x1" --batch $b --sparse 0.0045 --topx 10 --targets 256,320,384,448 2>&1 | grep "^{" >> gpurun_out/r06_launch_geometry_o7.txt; done
+  for bits in 4 3; do timeout 900 python $G --bits $bits --shapes "qkv7:4096x4096x3,o7:4096x4096x1,gateup7:4096x11008x2,down7:11008x4096x1" --sparse 0.0045 --topx 10 --targets 128,192,256,320,384,512,640,768,1024 2>&1 | grep "^{" >> gpurun_out/r06_launch_geometry_b1_s45.txt; done
+  timeout 900 python $G --shapes "qkv13:5120x5120x3,o13:5120x5120x1,gateup13:5120x13824x2,down13:13824x5120x1" --sparse 0.0045 --topx 10 --targets 256,384,512,640,768,1024,1280 2>&1 | grep "^{" >> gpurun_out/r06_launch_geometry_b1_13b65b.txt
+  timeout 900 python $G --bits 3 --shapes "qkv65:8192x8192x3,o65:8192x8192x1,gateup65:8192x22016x2,down65:22016x8192x1" --sparse 0.0045 --topx 10 --targets 256,384,512,768,1024,1536 2>&1 | grep "^{" >> gpurun_out/r06_launch_geometry_b1_13b65b.txt
+  bash tools/ab_libs.sh "tree4 tree5" "13b-w4-s45 7b-w4-s0" 3   # one chunk per K slice
+  bash tools/ab_libs.sh "tree5 tree6" "7b-w4-s0 7b-w4-s45 13b-w4-s45" 3   # two-step chunks for two-step slices
+  bash tools/ab_libs.sh "tree6 tree7" "65b-w3-s45" 2   # 3-bit op alone at batch 1 cut to one round
+  ;;
 ceiling)
   # product and loads-only kernels on ONE clock (graph wall per launch, same box, same session)
   (/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/stream_patterns.hip -o /tmp/sp 2>&1 | tail -3)
