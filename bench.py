@@ -166,7 +166,9 @@ def roofline_leg(seq, layers, bytes_per_op, cfg, config_name, fused):
         "frac_rocprof": None if kt_us is None else round(pass_bytes / n_launch / (kt_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
         "avg_kernel_us_rocprof": None if kt_us is None else round(kt_us, 3),
         "frac_rocprof_source": kt_source,
-        "kernel": f"sqllm_fused_matvec<{cfg['bits']},1>",
+        # the launches of a pass are routed per launch shape (sqllm_capi.hip: cols_pays_batch1): the fused kernel, or the column-lane kernel for the
+        # dense-only q/k/v group and down_proj (and the 3-bit gate/up)
+        "kernel": f"sqllm_fused_matvec<{cfg['bits']},1> / sqllm_fused_cols<{cfg['bits']},1> by launch shape",
         "avg_kernel_us": round(avg_us, 3),
         "launches_per_step": n_launch,
         "algorithmic_bytes_per_launch": int(pass_bytes / n_launch),
@@ -190,7 +192,7 @@ def rocprof_kernel_us_per_launch(config_name: str, fused: bool):
         calls, total = 0, 0.0
         for ln in lines:
             f = ln.split()
-            if len(f) >= 8 and f[0].startswith("sqllm::sqllm_fused_matvec"):
+            if len(f) >= 8 and (f[0].startswith("sqllm::sqllm_fused_matvec") or f[0].startswith("sqllm::sqllm_fused_cols")):  # (the pass's launches: both dense kernels)
                 try:
                     c, t = int(f[-6]), float(f[-5])
                 except ValueError:

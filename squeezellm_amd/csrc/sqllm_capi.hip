@@ -488,18 +488,55 @@ bool cols_pays(const sqllm_op* op, int n_ops) {
   return op->N >= 8192;
 }
 
+// ... and at BATCH 1 (the matvec operators; a *_batched call with one row) -- round 6, second session.  The column-lane kernel's loop is 1.5 vector + 1 LDS
+// instructions per weight at one row (vec in SGPRs: no broadcasts) against the fused kernel's 2.1 + 1; it had lost at batch 1 in round 3, before its ranges were cut
+// tile by tile and before groups ran as one launch.  Re-measured per launch shape (tools/experiments/launch_geometry.py --batch 1 --options cols_min_batch=1
+// against --batch 0; graph wall, column-lane against fused; profiles/r06_cols_batch1.txt):
+//                 o_proj (alone)   down_proj (alone)   q/k/v (3 ops)   gate/up (2 ops)
+//   7B  w4 s0        +12 %             -3.5 %             -11.5 %          +1.3 %
+//   7B  w3 s0        +13 %             -2 %               -6.7 %           -11 %
+//   13B w4 s0        +20 %             -11.5 %            -3.6 %           -2.5 %
+//   13B w3 s0        +38 %             -0.2 %             -8.3 %           -8 %
+//   65B w3 s0        +7.6 %            -6.7 %             -9.8 %           -1.3 %
+//   7B  w4 s45       +4.5 %            +1 %               -1.7 %           +18 %
+//   7B  w3 s45       +10.6 %           -2.7 %             -2.3 %           -9 %
+//   13B w4 s45       +27 %             +6.5 %             +2 %             +17 %
+//   13B w3 s45       +27 %             +9.7 %             +5.5 %           +6.1 %
+//   65B w3 s45       +15 %             +0.7 %             -5 %             +13 %
+// Dense-only launches of >= 16 MB win on it -- three-op groups always, a single op if it is tall (K >= 2 N: the square 65B o_proj loses), two-op groups at 3 bits.
+// With sparse roles in the grid (which have none of the fused path's role priorities and wide chunks here) only the 3-bit groups whose K cuts into even ranges
+// (K a multiple of 2048) up to 40 MB do: 7B q/k/v and gate/up.
+bool cols_pays_batch1(const sqllm_op* sum, int n_ops, bool sparse) {
+  const double mb = (double)sum->K * sum->N * sum->bits / 8e6;
+  if (mb < 16.0) return false;
+  if (!sparse) return n_ops >= 3 || (n_ops == 1 && sum->K >= 2ll * sum->N) || (n_ops == 2 && sum->bits == 3);
+  return sum->bits == 3 && n_ops >= 2 && sum->K % 2048 == 0 && mb <= 40.0;
+}
+
+static bool op_has_sparse(const sqllm_op* op) { return (op->rows && op->nnz > 0) || (op->full_rows && op->topX > 0); }
+
+// the routing test shared by single ops and groups: `sum` = the op, or the group as the one op it is to the kernel (the sum of its columns)
+static bool cols_route(const sqllm_op* sum, int n_ops, bool sparse) {
+  const int b = sum->batch <= 0 ? 1 : sum->batch;
+  const bool explicit_range = knobs().cols_min_batch.load(std::memory_order_relaxed) > 0 || knobs().cols_max_batch.load(std::memory_order_relaxed) > 0;
+  if (b == 1 && !explicit_range) return cols_pays_batch1(sum, n_ops, sparse);
+  return b >= cols_min_batch_of() && b <= cols_max_batch_of(sum) && cols_pays(sum, n_ops);
+}
+
 // a group of ops over one vec (q/k/v, gate/up) is judged as the one op it is to the kernel: the sum of its columns
 bool group_takes_cols_path(const sqllm_op* ops, int n) {
   sqllm_op sum = ops[0];
   long long N = 0;
-  for (int i = 0; i < n; ++i) N += ops[i].N;
+  bool sparse = false;
+  for (int i = 0; i < n; ++i) {
+    N += ops[i].N;
+    sparse = sparse || op_has_sparse(&ops[i]);
+  }
   sum.N = N > 0x7fffffff ? 0x7fffffff : (int)N;
-  return !takes_mfma_path(&ops[0], n) && sum.batch >= 1 && sum.batch >= cols_min_batch_of() && sum.batch <= cols_max_batch_of(&sum) && cols_pays(&sum, n);
+  return !takes_mfma_path(&ops[0], n) && cols_route(&sum, n, sparse);
 }
 
-bool takes_cols_path(const sqllm_op* op) {
-  return !takes_mfma_path(op) && op->batch >= 1 && op->batch >= cols_min_batch_of() && op->batch <= cols_max_batch_of(op) && cols_pays(op, 1);
-}
+bool takes_cols_path(const sqllm_op* op) { return !takes_mfma_path(op) && cols_route(op, 1, op_has_sparse(op)); }
 
 }  // namespace sqllm_host
 

@@ -64,7 +64,9 @@ def test_plan_geometry():
     p = _lib.plan_query(4, 4096, 4096)
     assert p["col_tiles"] == 64 and p["dense_blocks"] == p["col_tiles"] * p["k_slices"]
     assert p["dense_blocks"] == 512   # a small op alone in its launch: two workgroups per CU
-    assert _lib.plan_query(4, 11008, 4096)["dense_blocks"] == 960   # a large one alone: ~4 per CU
+    assert _lib.plan_query(4, 11008, 4096, nnz=202_899, topX=10)["dense_blocks"] == 960   # a large one alone (fused kernel: it has sparse terms): ~4 per CU
+    # ... dense-only, tall and >= 16 MB it takes the column-lane kernel at batch 1 too (round 6): ranges of the flattened (tile, unit) space, ~3 per CU
+    assert _lib.plan_query(4, 11008, 4096)["dense_blocks"] == 768
     assert p["csr_blocks"] == 0 and p["topx_blocks"] == 0 and p["grid_y"] == 1
     assert p["groups_per_wave"] % 32 == 0  # a K slice is whole workgroup steps (8 waves x 4 units)
     # every unit is covered exactly once
