@@ -87,6 +87,27 @@ def test_llama7b_decoder_layer_grouped(gpu, bits, sparse, topX):
     _check_layer(layers, gpu, batch=0, graph=True)
 
 
+@pytest.mark.parametrize("bits,sparse,topX", [(4, 0.0, 0), (3, 0.0045, 10), (3, 0.0, 0)], ids=["w4-s0", "w3-s45", "w3-s0"])
+@pytest.mark.parametrize("route", ["fused-only", "column-lane-everything"])
+def test_llama7b_decoder_layer_both_batch1_routes(gpu, bits, sparse, topX, route):
+    """Batch 1 is routed per launch shape since round 6 (sqllm_capi.hip: cols_pays_batch1 -- the dense-only q/k/v group and down_proj, the 3-bit
+    gate/up ... on the column-lane kernel, the rest on the fused kernel).  The default routing is test_llama7b_decoder_layer_grouped above; here
+    the same layers with EVERY launch on the fused kernel (cols_min_batch huge: the route those shapes had until then) and with every launch on the
+    column-lane kernel (cols_min_batch = cols_max_batch = 1), against the C oracle."""
+    from squeezellm_amd import _lib
+
+    layers = _decoder_layer("llama-7b", bits, sparse, topX, gpu, seed0=100 * bits + 7)
+    opts = {"cols_min_batch": 1 << 30} if route == "fused-only" else {"cols_min_batch": 1, "cols_max_batch": 1}
+    for k, v in opts.items():
+        _lib.set_option(k, v)
+    try:
+        _check_layer(layers, gpu, batch=0, graph=False)
+        _check_layer(layers, gpu, batch=1, graph=False)  # (the *_batched operators with one row take the same routes)
+    finally:
+        for k in opts:
+            _lib.set_option(k, 0)
+
+
 @pytest.mark.parametrize("batch", [1, 2, 3, 4, 5, 6, 7, 8, 12, 16])
 def test_llama13b_decoder_layer_grouped_batched(gpu, batch):
     """BASELINE configs[3]: 13B shapes, w4 s45, the *_batched operators at every row count of "batch 1..8" and beyond, grouped, by
