@@ -505,12 +505,13 @@ bool cols_pays(const sqllm_op* op, int n_ops) {
 //   65B w3 s45       +15 %             +0.7 %             -5 %             +13 %
 // Dense-only launches of >= 16 MB win on it -- three-op groups always, a single op if it is tall (K >= 2 N: the square 65B o_proj loses), two-op groups at 3 bits.
 // With sparse roles in the grid (which have none of the fused path's role priorities and wide chunks here) only the 3-bit groups whose K cuts into even ranges
-// (K a multiple of 2048) up to 40 MB do: 7B q/k/v and gate/up.
+// (K a multiple of 2048) up to 40 MB do: 7B q/k/v and gate/up -- and the 4-bit 7B q/k/v group, by a little.
 bool cols_pays_batch1(const sqllm_op* sum, int n_ops, bool sparse) {
   const double mb = (double)sum->K * sum->N * sum->bits / 8e6;
   if (mb < 16.0) return false;
   if (!sparse) return n_ops >= 3 || (n_ops == 1 && sum->K >= 2ll * sum->N) || (n_ops == 2 && sum->bits == 3);
-  return sum->bits == 3 && n_ops >= 2 && sum->K % 2048 == 0 && mb <= 40.0;
+  // (4-bit: the three-op group only -- 7B q/k/v -1.7 / -3.5 % on two boxes; its gate/up loses 18 %)
+  return sum->K % 2048 == 0 && mb <= 40.0 && n_ops >= (sum->bits == 3 ? 2 : 3);
 }
 
 static bool op_has_sparse(const sqllm_op* op) { return (op->rows && op->nnz > 0) || (op->full_rows && op->topX > 0); }
