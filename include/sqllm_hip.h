@@ -295,6 +295,9 @@ const char* sqllm_error_string(int code); /* static string for SQLLM_E_* and hip
  *                     batch tiles of the batch-1 kernel (tiles of exactly 1..8 rows).  Defaults (value 0 =
  *                     measured default, which depends on the bit width; get_option returns the stored 0): 4-bit 2..4 / 7
  *                     (9 for an op of <= 16 MB of packed weights alone in its launch), 3-bit 2..8 / 9.
+ *                     At ONE row (batch 1, or the matvec names) the defaults route by launch shape instead (round 6, sqllm_capi.hip: cols_pays_batch1 --
+ *                     dense-only launches of >= 16 MB that are a three-op group, a tall single op or a 3-bit two-op group, and the 7B-class sparse groups,
+ *                     take the column-lane kernel); an explicit cols_min_batch = 1 sends every one-row launch there, a huge cols_min_batch none.
  *                     With the two cols_* options at their defaults the column-lane kernel is further reserved
  *                     for what it measured faster on: 4-bit, groups of three or more ops (up to 4 rows) and single ops of
  *                     >= 20 MB packed weights (up to 6 rows); 3-bit, >= 16 MB at up to 4 rows or N >= 8192; setting either option
